@@ -1,0 +1,179 @@
+/* sa_hip.h -- C ABI of libsa_hip.so, the MI355X (gfx950) compute library behind the
+ * speech-anonymization ConvAE + gender-adversarial train step.
+ *
+ * The reference (viswavi/speech-anonymization) has no native / FFI boundary: the hot path is
+ * PyTorch ops reached from three Python seams.  This header is the boundary a
+ * maintainer binds instead (ctypes stub: INTEGRATION.md); each entry point cites the
+ * reference code whose arithmetic it replaces.  Conventions:
+ *   - plain C: pointers + sizes, no torch / HIP types; `stream` is a hipStream_t passed as void*
+ *     (torch.cuda.current_stream().cuda_stream); every call only ENQUEUES work on it;
+ *   - every buffer (inputs, outputs, saved tensors, workspaces) is caller-allocated device
+ *     memory; the library allocates nothing and keeps no state besides kernel attributes;
+ *   - return 0 on success, -EINVAL (-22) for bad arguments, -ENOSYS (-38) for a shape that is
+ *     not instantiated, or -(hipError_t) from the launch; nothing throws across the ABI;
+ *   - dtype: SA_F32 (0) or SA_BF16 (1) = storage type of activations and packed weights;
+ *     accumulation and all statistics are fp32 (fp64 in the tiny finalisers);
+ *   - activations are CHANNELS-LAST [B][L][C]; the reference's [B][C][L] tensors are never
+ *     materialised (C = 1 at both ends of the auto-encoder, so the module boundary
+ *     feats[B][T][80] -> recon[B][T][80] needs no conversion).
+ */
+#ifndef SA_HIP_H
+#define SA_HIP_H
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SA_F32 0
+#define SA_BF16 1
+#define SA_MAX_TAPS 5
+
+/* ---- implicit-GEMM convolution (sa_conv_gemm.hip) -------------------------------------
+ * Row-gather GEMM covering nn.Conv1d, nn.ConvTranspose1d(stride 2) and both data gradients
+ * (models/ConvAutoEncoder.py:141-172 encoder/decoder, :33-43 TDNN; backward via
+ * speechbrain_convae_train.py:241).  For base row m and phase ph < U the output row is
+ * o = m*U + ph and
+ *   y[b,o,co] = bias[co] + sum_{t<ntaps[ph]} sum_ci P(x)[b, m*SA + off[ph][t], ci] * W[widx[ph][t]][ci][co]
+ * rows outside [0,Lin) are zero.  P = prologue: v*s1[b][ci]+t1[b][ci] -> x*sigmoid(x) if swish
+ * -> v*s2[ci]+t2[ci] (any pointer may be NULL).  Epilogue: +bias, ReLU if relu, store, and if
+ * stats != NULL per-tile partial (sum, sumsq) of the stored values -> stats[B][ntiles][COUT][2]
+ * with ntiles = sa_conv_gemm_ntiles(Lout, U). */
+typedef struct SaTaps {
+  int ntaps[2];
+  int off[2][SA_MAX_TAPS];
+  int widx[2][SA_MAX_TAPS];
+} SaTaps;
+
+typedef struct SaConvArgs {
+  const void* x;
+  const void* wp;            /* sa_pack_weights image */
+  const float* bias;
+  void* y;
+  const float* s1; const float* t1;
+  const float* s2; const float* t2;
+  int swish;
+  int relu;
+  float* stats;
+  int B, Lin, Lout, ntiles;  /* ntiles, rowmin, nrows are filled in by the library */
+  int rowmin, nrows;
+  SaTaps taps;
+} SaConvArgs;
+
+int sa_conv_gemm(int dtype, int cin, int cout, int sa, int u, const SaConvArgs* a, void* stream);
+int sa_conv_gemm_ntiles(int Lout, int U);
+
+/* fp32 master weights -> fragment-major MFMA operand image (K = GEMM reduction channels,
+ * N = produced channels; element W(t,k,n) = src[k*sk + n*sn + t*st]).
+ * nn.Conv1d.weight [Cout][Cin][Kw]: forward sk=Kw, sn=Cin*Kw, st=1; dgrad sk=Cin*Kw, sn=Kw.
+ * nn.ConvTranspose1d.weight [Cin][Cout][Kw]: forward sk=Cout*Kw, sn=Kw; dgrad sk=Kw, sn=Cout*Kw. */
+int sa_pack_weights(int dtype, const float* src, void* dst, int ntaps, int K, int N, int sk, int sn,
+                    int st, void* stream);
+
+/* ---- weight gradients (sa_wgrad.hip) --------------------------------------------------
+ * dW[t][ci][co] = sum_b sum_{m<Mrows} P(x)[b, m*SA+off[t], ci] * dy[b, m*U+ph[t], co];
+ * grid (nchunk, ntaps, B), each workgroup covers `chunk` (multiple of 64) base rows and writes
+ * slabs[b][chunk][t][CIN][COUT]; sa_wgrad_reduce sums them in a fixed order into
+ * dst[ci*sk + co*sn + t*st]. */
+typedef struct SaWgradArgs {
+  const void* x;
+  const void* dy;
+  float* slabs;
+  const float* s1; const float* t1; const float* s2; const float* t2; int swish;
+  int B, Lin, Ldy, Mrows, chunk, nchunk;
+  int ntaps; int off[SA_MAX_TAPS]; int ph[SA_MAX_TAPS];
+} SaWgradArgs;
+
+int sa_wgrad(int dtype, int cin, int cout, int sa, int u, const SaWgradArgs* a, void* stream);
+int sa_wgrad_reduce(const float* slabs, float* dst, int nslab, int ntaps, int cin, int cout, int sk,
+                    int sn, int st, int accumulate, void* stream);
+
+/* ---- single-channel ends (sa_small.hip): encoder.0 Conv1d(1,32,15,p7) / decoder.8
+ * Conv1d(32,1,15,p7), models/ConvAutoEncoder.py:142,171 ------------------------------- */
+int sa_conv1toC(int dtype, const float* x, const float* w, const float* bias, void* y, int B, int L,
+                int flip, float* stats, void* stream);          /* stats [B][ntiles][32][2] */
+int sa_conv1toC_ntiles(int L);
+int sa_convCto1(int dtype, const void* x, const float* w, const float* bias, float* y, int B, int L,
+                const float* s1, const float* t1, int swish, void* stream);
+int sa_wgrad1C(int dtype, const float* u, const void* v, float* slabs, int B, int L, int chunk,
+               int flip, const float* s1, const float* t1, int swish, void* stream);
+int sa_wgrad1C_nchunk(int L, int chunk);
+int sa_sum_slabs(const float* slabs, float* dst, int nslab, int n, int accumulate, void* stream);
+
+/* ---- normalisation / activation backward + statistics finalisers (sa_elementwise.hip):
+ * nn.InstanceNorm1d(affine), nn.BatchNorm1d (train), x*sigmoid(x), GradReverse
+ * (models/ConvAutoEncoder.py:12-28,33-44,119-120,146-169) ---------------------------- */
+typedef struct SaEwArgs {
+  const void* g; const void* g2; const void* x; void* out;
+  const float* s1; const float* t1;
+  const float* mean; const float* rstd;
+  const float* c1; const float* c2; const float* c3;
+  int actbwd, xp_is_act, relu_mask, bstride;
+  float* stats;
+  int B, L, ntiles;
+} SaEwArgs;
+
+int sa_ew_stats(int dtype, int C, const SaEwArgs* a, void* stream);
+int sa_ew_apply(int dtype, int C, const SaEwArgs* a, void* stream);
+int sa_ew_ntiles(int L);
+int sa_act_stats(int dtype, int C, const void* x, const float* s1, const float* t1, int swish,
+                 float* stats, int B, int L, void* stream);
+int sa_sum_partials(const float* slabs, float* dst, int nbatch, int nslab, int n, void* stream);
+int sa_fin_in_fwd(const float* sums, int B, int C, int n, const float* gamma, const float* beta,
+                  float eps, float* mean, float* rstd, float* scale, float* shift, void* stream);
+int sa_fin_bn_fwd(const float* sums, int C, double count, const float* gamma, const float* beta,
+                  float eps, float momentum, float* run_mean, float* run_var, float* mean,
+                  float* rstd, float* scale, float* shift, void* stream);
+int sa_fin_norm_bwd(const float* sums, const float* lsums, int groups, int C, double n,
+                    const float* gamma, const float* mean, const float* rstd, float sign, float* c1,
+                    float* c2, float* c3, float* dgamma, float* dbeta, void* stream);
+int sa_fin_bias(const float* sums, int B, int C, float* db, void* stream);
+
+/* ---- classifier head + losses (sa_head.hip): TDNNSexClassifier.forward reshape + pooling
+ * (models/ConvAutoEncoder.py:61-66), classify (:47-55), log_softmax (:68); losses at
+ * speechbrain_convae_train.py:105-108; utils/cosine_similarity_loss.py:53-56 ---------- */
+int sa_pool_fwd(int dtype, const void* r, const float* scale, const float* shift, float* part, int B,
+                int L, void* stream);                            /* part [B][ntiles][128][2] */
+int sa_pool_ntiles(int L);
+int sa_pool_fin(const float* sums, int B, int n, const float* noise, float eps, float* pooled,
+                float* mean, float* stdraw, void* stream);
+int sa_pool_bwd(int dtype, const void* r, const float* scale, const float* shift,
+                const float* dpooled, const float* mean, const float* stdraw, void* g, int B, int L,
+                void* stream);
+int sa_dense(const float* X, int lda, const float* ps, const float* pt, const float* W, int sbk,
+             int sbn, const float* bias, float* Y, int ldy, int M, int N, int K, int relu,
+             void* stream);
+int sa_colsums(const float* X, const float* H, const float* hmean, const float* hrstd, int M, int N,
+               float* sums, void* stream);
+int sa_bn2d_bwd(const float* G, const float* H, const float* sums, double count, const float* gamma,
+                const float* mean, const float* rstd, int relu_mask, int M, int N, float* dH,
+                void* stream);
+int sa_dense_wgrad(const float* dY, const float* X, const float* ps, const float* pt, int M, int N,
+                   int K, float* dW, void* stream);
+int sa_log_softmax(const float* X, float* Y, int M, int N, void* stream);
+int sa_log_softmax_bwd(const float* dY, const float* Y, float* dX, int M, int N, void* stream);
+int sa_loss_workspace_bytes(void);
+int sa_recon_loss(const float* a, const float* b, long long n, int kind, float* grad, float* loss,
+                  void* workspace, void* stream);                /* kind 0 = L1, 1 = MSE */
+int sa_cls_losses(const float* logp, const long long* label, int B, int NC, float* out, float* dnll,
+                  float* dconf, void* stream);                   /* out = (nll, confusion) */
+int sa_cosine_loss(const float* x1, const float* x2, int B, int S, int D, float* rowloss,
+                   float* loss, float* dx1, void* stream);
+
+/* ---- k-NN mutual information (sa_mi.hip): utils/ClusterMI.py:88-121,
+ * utils/GroupSamplingMI.py:49-61, utils/mi_loss.py:14-17 ------------------------------ */
+int sa_cluster_mi(const float* X, const long long* y, const long long* idx, int iters, int n, int D,
+                  int ncls, int k, float* mi, void* stream);
+
+/* ---- feature front-end (sa_fbank.hip): speechbrain Fbank + InputNormalization at
+ * speechbrain_convae_train.py:58-63,82-87 (convae.yaml:93-95,269-271,289-292) --------- */
+int sa_fbank(const float* wav, int B, int N, const float* window, const float* dft,
+             const float* mel, float* feats, float* tilemax, void* stream);
+int sa_fbank_ntiles(int T);
+int sa_fbank_normalize(const float* feats, const float* tilemax, int B, int T, int Tp,
+                       const float* lens, float top_db, int batch_max, int update, int epoch,
+                       int update_until_epoch, float* state, float* scratch, float* out,
+                       void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SA_HIP_H */

@@ -1,0 +1,117 @@
+"""ctypes binding of libsa_hip.so (the C ABI declared in include/sa_hip.h).
+
+The product path has NO CPU fallback: if the library is missing, or a call returns a
+non-zero code, this module raises.  torch is used only for device memory and streams.
+"""
+import ctypes as C
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libsa_hip.so")
+
+F32, BF16 = 0, 1
+MAX_TAPS = 5
+
+c_fp = C.POINTER(C.c_float)
+vp = C.c_void_p
+
+
+class SaTaps(C.Structure):
+    _fields_ = [("ntaps", C.c_int * 2), ("off", (C.c_int * MAX_TAPS) * 2),
+                ("widx", (C.c_int * MAX_TAPS) * 2)]
+
+
+class SaConvArgs(C.Structure):
+    _fields_ = [("x", vp), ("wp", vp), ("bias", vp), ("y", vp),
+                ("s1", vp), ("t1", vp), ("s2", vp), ("t2", vp),
+                ("swish", C.c_int), ("relu", C.c_int), ("stats", vp),
+                ("B", C.c_int), ("Lin", C.c_int), ("Lout", C.c_int), ("ntiles", C.c_int),
+                ("rowmin", C.c_int), ("nrows", C.c_int), ("taps", SaTaps)]
+
+
+class SaWgradArgs(C.Structure):
+    _fields_ = [("x", vp), ("dy", vp), ("slabs", vp),
+                ("s1", vp), ("t1", vp), ("s2", vp), ("t2", vp), ("swish", C.c_int),
+                ("B", C.c_int), ("Lin", C.c_int), ("Ldy", C.c_int), ("Mrows", C.c_int),
+                ("chunk", C.c_int), ("nchunk", C.c_int),
+                ("ntaps", C.c_int), ("off", C.c_int * MAX_TAPS), ("ph", C.c_int * MAX_TAPS)]
+
+
+class SaEwArgs(C.Structure):
+    _fields_ = [("g", vp), ("g2", vp), ("x", vp), ("out", vp),
+                ("s1", vp), ("t1", vp), ("mean", vp), ("rstd", vp),
+                ("c1", vp), ("c2", vp), ("c3", vp),
+                ("actbwd", C.c_int), ("xp_is_act", C.c_int), ("relu_mask", C.c_int),
+                ("bstride", C.c_int), ("stats", vp),
+                ("B", C.c_int), ("L", C.c_int), ("ntiles", C.c_int)]
+
+
+# every symbol include/sa_hip.h declares (checked by tests/test_abi.py on CPU)
+SYMBOLS = [
+    "sa_conv_gemm", "sa_conv_gemm_ntiles", "sa_pack_weights", "sa_wgrad", "sa_wgrad_reduce",
+    "sa_conv1toC", "sa_conv1toC_ntiles", "sa_convCto1", "sa_wgrad1C", "sa_wgrad1C_nchunk",
+    "sa_sum_slabs", "sa_ew_stats", "sa_ew_apply", "sa_ew_ntiles", "sa_act_stats",
+    "sa_sum_partials", "sa_fin_in_fwd", "sa_fin_bn_fwd", "sa_fin_norm_bwd", "sa_fin_bias",
+    "sa_pool_fwd", "sa_pool_ntiles", "sa_pool_fin", "sa_pool_bwd", "sa_dense", "sa_colsums",
+    "sa_bn2d_bwd", "sa_dense_wgrad", "sa_log_softmax", "sa_log_softmax_bwd",
+    "sa_loss_workspace_bytes", "sa_recon_loss", "sa_cls_losses", "sa_cosine_loss",
+    "sa_cluster_mi", "sa_fbank", "sa_fbank_ntiles", "sa_fbank_normalize",
+]
+
+_lib = None
+
+
+class SaHipError(RuntimeError):
+    pass
+
+
+def load():
+    """Load libsa_hip.so; raises if it has not been built (no fallback)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise SaHipError(
+                f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; "
+                "g.build()'` (hipcc --offload-arch=gfx950). There is no CPU fallback.")
+        _lib = C.CDLL(LIB_PATH)
+        for s in SYMBOLS:
+            getattr(_lib, s).restype = C.c_int
+    return _lib
+
+
+def stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def ptr(t):
+    """device pointer of a tensor (None -> NULL)."""
+    if t is None:
+        return None
+    assert t.is_cuda and t.is_contiguous(), "HIP kernels take contiguous device tensors"
+    return C.c_void_p(t.data_ptr())
+
+
+def check(rc, what):
+    if rc != 0:
+        raise SaHipError(f"{what} failed with code {rc}")
+
+
+def dt_code(dtype):
+    if dtype == torch.float32:
+        return F32
+    if dtype == torch.bfloat16:
+        return BF16
+    raise SaHipError(f"unsupported activation dtype {dtype}")
+
+
+def make_taps(phases):
+    """phases: list (len U) of lists of (row_offset, weight_index)."""
+    t = SaTaps()
+    for ph, lst in enumerate(phases):
+        t.ntaps[ph] = len(lst)
+        for i, (off, wi) in enumerate(lst):
+            t.off[ph][i] = off
+            t.widx[ph][i] = wi
+    return t

@@ -1,0 +1,101 @@
+// Common device helpers for the speech-anonymization HIP library (gfx950 / CDNA4 only).
+//
+// Data layout used by every kernel in this library: activations are CHANNELS-LAST,
+// [B][L][C] with C contiguous ("rows" = positions on the flattened T*80 axis the reference
+// ConvAutoencoder convolves over, models/ConvAutoEncoder.py:181-188).  The reduction
+// dimension of conv forward / dgrad (channels) is then contiguous, which is what the MFMA
+// operand fragments want (8 consecutive k per lane for v_mfma_f32_32x32x16_bf16).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "../../include/sa_hip.h"
+
+typedef __bf16 bf16_t;
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+#define SA_WAVE 64
+
+
+// ---- 16-byte chunk <-> float[VEC] -------------------------------------------------
+template <typename T> struct Tr;
+
+template <> struct Tr<float> {
+  static constexpr int VEC = 4;
+  static constexpr int KS = 2;           // k per v_mfma_f32_32x32x2_f32
+  typedef float Frag;
+  __device__ static inline void unpack(const uint4& u, float* f) {
+    f[0] = __uint_as_float(u.x); f[1] = __uint_as_float(u.y);
+    f[2] = __uint_as_float(u.z); f[3] = __uint_as_float(u.w);
+  }
+  __device__ static inline uint4 pack(const float* f) {
+    return make_uint4(__float_as_uint(f[0]), __float_as_uint(f[1]),
+                      __float_as_uint(f[2]), __float_as_uint(f[3]));
+  }
+  __device__ static inline float to_f(float v) { return v; }
+  __device__ static inline float from_f(float v) { return v; }
+  __device__ static inline f32x16 mfma(Frag a, Frag b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
+  }
+};
+
+__device__ static inline uint32_t sa_pack_bf16x2(float lo, float hi) {
+  union { bf16_t b[2]; uint32_t u; } cv;
+  cv.b[0] = (bf16_t)lo; cv.b[1] = (bf16_t)hi;     // v_cvt_pk_bf16_f32 (RNE, NaN-safe)
+  return cv.u;
+}
+
+template <> struct Tr<bf16_t> {
+  static constexpr int VEC = 8;
+  static constexpr int KS = 16;          // k per v_mfma_f32_32x32x16_bf16
+  typedef bf16x8 Frag;
+  __device__ static inline void unpack(const uint4& u, float* f) {
+    f[0] = __uint_as_float(u.x << 16); f[1] = __uint_as_float(u.x & 0xffff0000u);
+    f[2] = __uint_as_float(u.y << 16); f[3] = __uint_as_float(u.y & 0xffff0000u);
+    f[4] = __uint_as_float(u.z << 16); f[5] = __uint_as_float(u.z & 0xffff0000u);
+    f[6] = __uint_as_float(u.w << 16); f[7] = __uint_as_float(u.w & 0xffff0000u);
+  }
+  __device__ static inline uint4 pack(const float* f) {
+    return make_uint4(sa_pack_bf16x2(f[0], f[1]), sa_pack_bf16x2(f[2], f[3]),
+                      sa_pack_bf16x2(f[4], f[5]), sa_pack_bf16x2(f[6], f[7]));
+  }
+  __device__ static inline float to_f(bf16_t v) { return (float)v; }
+  __device__ static inline bf16_t from_f(float v) { return (bf16_t)v; }
+  __device__ static inline f32x16 mfma(Frag a, Frag b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+  }
+};
+
+// x * sigmoid(x): the reference's "GLU" (models/ConvAutoEncoder.py:119-120)
+__device__ static inline float sa_swish(float v) { return v / (1.0f + __expf(-v)); }
+// d/dv [v * sigmoid(v)] = s * (1 + v * (1 - s))
+__device__ static inline float sa_swish_grad(float v) {
+  float s = 1.0f / (1.0f + __expf(-v));
+  return s * (1.0f + v * (1.0f - s));
+}
+
+// Row of the C/D accumulator of a 32x32 MFMA held in register `reg` of lane `lane`
+// (col = lane & 31): cdna_hip_programming.md section 3.
+__device__ static inline int sa_acc_row(int reg, int lane) {
+  return (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5);
+}
+
+__device__ static inline float sa_wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ static inline double sa_wave_sum_d(double v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ static inline float sa_wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+
+// ABI structs (SaTaps, SaConvArgs, SaWgradArgs, SaEwArgs) live in include/sa_hip.h
+static inline int sa_div_up(int a, int b) { return (a + b - 1) / b; }

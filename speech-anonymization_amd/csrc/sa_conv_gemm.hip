@@ -1,0 +1,263 @@
+// Implicit-GEMM 1-D convolution on MFMA (gfx950), channels-last.
+//
+// Replaces the cuDNN/ATen conv1d / conv_transpose1d forward and their data gradients that
+// the reference reaches from models/ConvAutoEncoder.py:141-172 (encoder / decoder stacks)
+// and :33-43 (TDNN convs of the sex classifier).
+//
+// One workgroup (4 waves) produces 128 output rows x COUT channels of one utterance:
+//   prologue : the input rows it needs (128*SA/U + halo) are read ONCE from HBM with
+//              16-byte coalesced loads, transformed on the fly (InstanceNorm/BatchNorm
+//              affine + x*sigmoid(x), i.e. the producer's normalisation is applied here
+//              instead of in a separate pass) and staged in LDS;
+//   main loop: per tap and 16-deep (bf16) / 2-deep (f32) k-step, A fragments come from
+//              LDS (ds_read_b128, padded pitch => conflict-free), B fragments (weights,
+//              pre-packed fragment-major, L2-resident) straight from global memory;
+//              v_mfma_f32_32x32x16_bf16 / v_mfma_f32_32x32x2_f32, fp32 accumulate;
+//   epilogue : bias (+ReLU), transpose through LDS, 16-byte coalesced stores, and the
+//              per-(utterance, channel) sum / sum-of-squares of the stored values written
+//              as a per-tile partial slab (deterministic two-level reduction; no atomics).
+#include "sa_common.h"
+
+template <typename T, int CIN, int COUT, int SA, int U>
+struct ConvCfg {
+  typedef Tr<T> tr;
+  static constexpr int VEC = tr::VEC;
+  static constexpr int KS = tr::KS;
+  static constexpr int KSTEPS = CIN / KS;
+  static constexpr int NT = COUT / 32;
+  static constexpr int VT = NT * U;                 // virtual n-tiles (phase, n-tile)
+  static constexpr int BMB = 128 / U;               // base rows per workgroup
+  static constexpr int WN = VT >= 4 ? 4 : VT;       // waves along N
+  static constexpr int WM = 4 / WN;                 // waves along M
+  static constexpr int VPW = VT / WN;               // virtual n-tiles per wave
+  static constexpr int MT = BMB / (32 * WM);        // 32-row m-tiles per wave
+  static constexpr int APITCH = CIN + (sizeof(T) == 2 ? 8 : 1);
+  static constexpr int OPITCH = COUT + (sizeof(T) == 2 ? 8 : 4);
+  static constexpr int CHI = CIN / VEC;             // 16-byte chunks per input row
+  static constexpr int RPPI = 256 / CHI;
+  static constexpr int CHO = COUT / VEC;
+  static constexpr int RPPO = 256 / CHO;
+  static_assert(MT >= 1 && VT % WN == 0, "tile shape");
+  static size_t lds_bytes(int nrows) {
+    size_t a = (size_t)nrows * APITCH * sizeof(T);
+    size_t o = (size_t)128 * OPITCH * sizeof(T);
+    size_t m = a > o ? a : o;
+    m = (m + 15) & ~(size_t)15;
+    return m + (size_t)RPPO * COUT * 2 * sizeof(float);
+  }
+  static size_t red_off(int nrows) {
+    size_t a = (size_t)nrows * APITCH * sizeof(T);
+    size_t o = (size_t)128 * OPITCH * sizeof(T);
+    size_t m = a > o ? a : o;
+    return (m + 15) & ~(size_t)15;
+  }
+};
+
+template <typename T, int CIN, int COUT, int SA, int U>
+__global__ __launch_bounds__(256) void sa_conv_gemm_kernel(SaConvArgs a, int red_off) {
+  typedef ConvCfg<T, CIN, COUT, SA, U> C;
+  typedef Tr<T> tr;
+  typedef typename tr::Frag Frag;
+  constexpr int VEC = C::VEC;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  T* As = reinterpret_cast<T*>(smem);
+  T* Os = reinterpret_cast<T*>(smem);                       // overlays As after the main loop
+  float* red = reinterpret_cast<float*>(smem + red_off);
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tile = blockIdx.x, b = blockIdx.y;
+  const int m0 = tile * C::BMB;
+
+  // ---------------- prologue: stage + transform the input rows --------------------
+  {
+    const int c = tid % C::CHI, r0 = tid / C::CHI;
+    float s1[VEC], t1[VEC], s2[VEC], t2[VEC];
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) {
+      s1[j] = a.s1 ? a.s1[(size_t)b * CIN + c * VEC + j] : 1.0f;
+      t1[j] = a.t1 ? a.t1[(size_t)b * CIN + c * VEC + j] : 0.0f;
+      s2[j] = a.s2 ? a.s2[c * VEC + j] : 1.0f;
+      t2[j] = a.t2 ? a.t2[c * VEC + j] : 0.0f;
+    }
+    const bool has1 = a.s1 != nullptr, has2 = a.s2 != nullptr, sw = a.swish != 0;
+    const T* xb = reinterpret_cast<const T*>(a.x) + (size_t)b * a.Lin * CIN + c * VEC;
+    const int gbase = m0 * SA + a.rowmin;
+    for (int r = r0; r < a.nrows; r += C::RPPI) {
+      const int g = gbase + r;
+      uint4 u = make_uint4(0, 0, 0, 0);
+      if (g >= 0 && g < a.Lin) {
+        u = *reinterpret_cast<const uint4*>(xb + (size_t)g * CIN);
+        if (has1 || has2 || sw) {
+          float f[VEC];
+          tr::unpack(u, f);
+#pragma unroll
+          for (int j = 0; j < VEC; ++j) {
+            float v = f[j];
+            if (has1) v = fmaf(v, s1[j], t1[j]);
+            if (sw) v = sa_swish(v);
+            if (has2) v = fmaf(v, s2[j], t2[j]);
+            f[j] = v;
+          }
+          u = tr::pack(f);
+        }
+      }
+      T* dst = As + (size_t)r * C::APITCH + c * VEC;
+      if constexpr (sizeof(T) == 2) {
+        *reinterpret_cast<uint4*>(dst) = u;
+      } else {
+        float* d = reinterpret_cast<float*>(dst);
+        d[0] = __uint_as_float(u.x); d[1] = __uint_as_float(u.y);
+        d[2] = __uint_as_float(u.z); d[3] = __uint_as_float(u.w);
+      }
+    }
+  }
+  __syncthreads();
+
+  // ---------------- main loop: MFMA over taps x channels -------------------------
+  const int wn = wave % C::WN, wm = wave / C::WN;
+  f32x16 acc[C::VPW][C::MT];
+#pragma unroll
+  for (int v = 0; v < C::VPW; ++v)
+#pragma unroll
+    for (int mt = 0; mt < C::MT; ++mt)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) acc[v][mt][i] = 0.0f;
+
+  const Frag* wp = reinterpret_cast<const Frag*>(a.wp);
+#pragma unroll
+  for (int v = 0; v < C::VPW; ++v) {
+    const int vt = wn + v * C::WN;
+    const int ph = vt / C::NT, nt = vt % C::NT;
+    const int ntaps = a.taps.ntaps[ph];
+    for (int ti = 0; ti < ntaps; ++ti) {
+      const int off = a.taps.off[ph][ti] - a.rowmin;
+      const Frag* wt = wp + ((size_t)a.taps.widx[ph][ti] * C::KSTEPS * C::NT + nt) * 64 + lane;
+      const T* arow = As + (size_t)((wm * C::MT * 32 + (lane & 31)) * SA + off) * C::APITCH
+                      + (lane >> 5) * (C::KS / 2);
+#pragma unroll 4
+      for (int ks = 0; ks < C::KSTEPS; ++ks) {
+        const Frag bf = wt[(size_t)ks * C::NT * 64];
+#pragma unroll
+        for (int mt = 0; mt < C::MT; ++mt) {
+          const Frag af = *reinterpret_cast<const Frag*>(arow + (size_t)mt * 32 * SA * C::APITCH
+                                                         + ks * C::KS);
+          acc[v][mt] = tr::mfma(af, bf, acc[v][mt]);
+        }
+      }
+    }
+  }
+  __syncthreads();                                   // every wave is done reading As
+
+  // ---------------- epilogue: bias/ReLU -> LDS transpose -> coalesced store ------
+#pragma unroll
+  for (int v = 0; v < C::VPW; ++v) {
+    const int vt = wn + v * C::WN;
+    const int ph = vt / C::NT, nt = vt % C::NT;
+    const int col = nt * 32 + (lane & 31);
+    const float bv = a.bias ? a.bias[col] : 0.0f;
+#pragma unroll
+    for (int mt = 0; mt < C::MT; ++mt) {
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const int m = wm * C::MT * 32 + mt * 32 + sa_acc_row(i, lane);
+        float val = acc[v][mt][i] + bv;
+        if (a.relu) val = fmaxf(val, 0.0f);
+        Os[(size_t)(m * U + ph) * C::OPITCH + col] = tr::from_f(val);
+      }
+    }
+  }
+  __syncthreads();
+  {
+    const int c = tid % C::CHO, r0 = tid / C::CHO;
+    float ssum[VEC], ssq[VEC];
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) { ssum[j] = 0.0f; ssq[j] = 0.0f; }
+    T* yb = reinterpret_cast<T*>(a.y) + (size_t)b * a.Lout * COUT + c * VEC;
+    const int o0 = m0 * U;
+    for (int r = r0; r < 128; r += C::RPPO) {
+      const int o = o0 + r;
+      if (o < a.Lout) {
+        const uint4 u = *reinterpret_cast<const uint4*>(Os + (size_t)r * C::OPITCH + c * VEC);
+        *reinterpret_cast<uint4*>(yb + (size_t)o * COUT) = u;
+        if (a.stats) {
+          float f[VEC];
+          tr::unpack(u, f);
+#pragma unroll
+          for (int j = 0; j < VEC; ++j) { ssum[j] += f[j]; ssq[j] = fmaf(f[j], f[j], ssq[j]); }
+        }
+      }
+    }
+    if (a.stats) {
+#pragma unroll
+      for (int j = 0; j < VEC; ++j) {
+        red[((size_t)r0 * COUT + c * VEC + j) * 2 + 0] = ssum[j];
+        red[((size_t)r0 * COUT + c * VEC + j) * 2 + 1] = ssq[j];
+      }
+    }
+  }
+  if (a.stats) {
+    __syncthreads();
+    if (tid < COUT) {
+      float s = 0.0f, q = 0.0f;
+      for (int r = 0; r < C::RPPO; ++r) {
+        s += red[((size_t)r * COUT + tid) * 2 + 0];
+        q += red[((size_t)r * COUT + tid) * 2 + 1];
+      }
+      float* dst = a.stats + (((size_t)b * a.ntiles + tile) * COUT + tid) * 2;
+      dst[0] = s; dst[1] = q;
+    }
+  }
+}
+
+template <typename T, int CIN, int COUT, int SA, int U>
+static int launch_cfg(const SaConvArgs& a, hipStream_t st) {
+  typedef ConvCfg<T, CIN, COUT, SA, U> C;
+  SaConvArgs args = a;
+  args.ntiles = sa_div_up(sa_div_up(a.Lout, U), C::BMB);
+  // host-side shape check: every LDS row the main loop touches must be staged
+  int omin = 1 << 30, omax = -(1 << 30);
+  for (int ph = 0; ph < U; ++ph)
+    for (int t = 0; t < a.taps.ntaps[ph]; ++t) {
+      omin = a.taps.off[ph][t] < omin ? a.taps.off[ph][t] : omin;
+      omax = a.taps.off[ph][t] > omax ? a.taps.off[ph][t] : omax;
+    }
+  if (omin > omax) return -22;
+  args.rowmin = omin;
+  args.nrows = (C::BMB - 1) * SA + (omax - omin) + 1;
+  const size_t lds = C::lds_bytes(args.nrows);
+  if (lds > 160 * 1024) return -12;
+  auto kern = sa_conv_gemm_kernel<T, CIN, COUT, SA, U>;
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e != hipSuccess) return -(int)e;
+    attr_set = true;
+  }
+  dim3 grid(args.ntiles, a.B);
+  hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, args, (int)C::red_off(args.nrows));
+  hipError_t e = hipGetLastError();
+  return e == hipSuccess ? 0 : -(int)e;
+}
+
+// number of (sum, sumsq) partial tiles per utterance the epilogue writes
+extern "C" int sa_conv_gemm_ntiles(int Lout, int U) { return sa_div_up(sa_div_up(Lout, U), 128 / U); }
+
+#define SA_CONV_CASE(CI, CO, S, UU)                                              \
+  if (cin == CI && cout == CO && sa == S && u == UU)                             \
+    return dtype == SA_BF16 ? launch_cfg<bf16_t, CI, CO, S, UU>(*a, st)          \
+                            : launch_cfg<float, CI, CO, S, UU>(*a, st);
+
+// C-ABI entry (see include/sa_hip.h).  Returns 0, or a negative hipError_t / errno.
+extern "C" int sa_conv_gemm(int dtype, int cin, int cout, int sa, int u, const SaConvArgs* a,
+                            void* stream) {
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  if (!a || !a->x || !a->wp || !a->y || a->B <= 0 || a->Lin <= 0 || a->Lout <= 0) return -22;
+  SA_CONV_CASE(32, 64, 2, 1)
+  SA_CONV_CASE(64, 64, 1, 1)
+  SA_CONV_CASE(64, 128, 2, 1)
+  SA_CONV_CASE(128, 128, 1, 1)
+  SA_CONV_CASE(128, 64, 1, 2)
+  SA_CONV_CASE(64, 32, 1, 2)
+  return -38;                   // ENOSYS: shape not instantiated
+}

@@ -1,0 +1,326 @@
+// Normalisation / activation backward passes and the statistics finalisers (HBM-bound).
+//
+// Forward normalisation is never a pass of its own: InstanceNorm1d / BatchNorm1d statistics
+// come out of the producing conv's epilogue (sa_conv_gemm) as per-tile partial sums and the
+// affine + x*sigmoid(x) is applied in the consuming kernel's prologue.  Backward needs two
+// phases per normalised tensor (the gradient of a mean couples every row):
+//   sa_ew_stats : g' = (g [+ g2]) * swish'(z)           -> sum g', sum g'*xhat per (b, c)
+//   sa_fin_*    : tiny kernels turning sums into coefficients (and d gamma / d beta)
+//   sa_ew_apply : d y = (c1*g' + c2*x + c3) [* (x > 0)]  -> + per-(b,c) sum for bias grads
+// Reference semantics: nn.InstanceNorm1d(affine, eps 1e-5, biased var), nn.BatchNorm1d in
+// train mode, x*sigmoid(x) (models/ConvAutoEncoder.py:119-120,146-169,33-43), GradReverse
+// (:12-28) folded into the coefficients as a sign.
+#include "sa_common.h"
+
+
+#define SA_EW_ROWS 256
+
+template <typename T, int C, bool APPLY>
+__global__ __launch_bounds__(256) void sa_ew_kernel(SaEwArgs a) {
+  typedef Tr<T> tr;
+  constexpr int VEC = tr::VEC, CH = C / VEC, RPP = 256 / CH;
+  __shared__ float red[RPP][C][2];
+  const int tid = threadIdx.x, b = blockIdx.y, tile = blockIdx.x;
+  const int c = tid % CH, r0 = tid / CH;
+  const size_t cb1 = (size_t)b * C + c * VEC;                   // (b,c) indexed arrays (s1,t1)
+  const size_t cbn = (size_t)b * a.bstride + c * VEC;           // mean/rstd/c1..c3
+  float s1[VEC], t1[VEC], mu[VEC], rs[VEC], k1[VEC], k2[VEC], k3[VEC], acc0[VEC], acc1[VEC];
+#pragma unroll
+  for (int j = 0; j < VEC; ++j) {
+    s1[j] = a.s1 ? a.s1[cb1 + j] : 1.0f;
+    t1[j] = a.t1 ? a.t1[cb1 + j] : 0.0f;
+    mu[j] = a.mean ? a.mean[cbn + j] : 0.0f;
+    rs[j] = a.rstd ? a.rstd[cbn + j] : 1.0f;
+    k1[j] = (APPLY && a.c1) ? a.c1[cbn + j] : 1.0f;
+    k2[j] = (APPLY && a.c2) ? a.c2[cbn + j] : 0.0f;
+    k3[j] = (APPLY && a.c3) ? a.c3[cbn + j] : 0.0f;
+    acc0[j] = 0.0f; acc1[j] = 0.0f;
+  }
+  const size_t base = (size_t)b * a.L * C + c * VEC;
+  const T* gp = reinterpret_cast<const T*>(a.g) + base;
+  const T* g2p = a.g2 ? reinterpret_cast<const T*>(a.g2) + base : nullptr;
+  const T* xp = reinterpret_cast<const T*>(a.x) + base;
+  T* op = a.out ? reinterpret_cast<T*>(a.out) + base : nullptr;
+  const int lbeg = tile * SA_EW_ROWS;
+  for (int r = r0; r < SA_EW_ROWS; r += RPP) {
+    const int l = lbeg + r;
+    if (l >= a.L) break;
+    float g[VEC], x[VEC], o[VEC];
+    tr::unpack(*reinterpret_cast<const uint4*>(gp + (size_t)l * C), g);
+    tr::unpack(*reinterpret_cast<const uint4*>(xp + (size_t)l * C), x);
+    if (g2p) {
+      float g2[VEC];
+      tr::unpack(*reinterpret_cast<const uint4*>(g2p + (size_t)l * C), g2);
+#pragma unroll
+      for (int j = 0; j < VEC; ++j) g[j] += g2[j];
+    }
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) {
+      const float z = fmaf(x[j], s1[j], t1[j]);
+      const float xv = a.xp_is_act ? sa_swish(z) : x[j];
+      if (APPLY) {
+        float v = fmaf(k1[j], g[j], fmaf(k2[j], xv, k3[j]));
+        if (a.relu_mask && !(x[j] > 0.0f)) v = 0.0f;
+        o[j] = v;
+      } else {
+        o[j] = a.actbwd ? g[j] * sa_swish_grad(z) : g[j];
+      }
+    }
+    uint4 u = tr::pack(o);
+    if (op) *reinterpret_cast<uint4*>(op + (size_t)l * C) = u;
+    if (a.stats) {
+      tr::unpack(u, o);                                  // statistics of the STORED values
+#pragma unroll
+      for (int j = 0; j < VEC; ++j) {
+        acc0[j] += o[j];
+        if (!APPLY) {
+          const float z = fmaf(x[j], s1[j], t1[j]);
+          const float xv = a.xp_is_act ? sa_swish(z) : x[j];
+          acc1[j] = fmaf(o[j], (xv - mu[j]) * rs[j], acc1[j]);
+        }
+      }
+    }
+  }
+  if (a.stats) {
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) { red[r0][c * VEC + j][0] = acc0[j]; red[r0][c * VEC + j][1] = acc1[j]; }
+    __syncthreads();
+    if (tid < C) {
+      float s = 0.f, q = 0.f;
+      for (int r = 0; r < RPP; ++r) { s += red[r][tid][0]; q += red[r][tid][1]; }
+      float* d = a.stats + (((size_t)b * a.ntiles + tile) * C + tid) * 2;
+      d[0] = s; d[1] = q;
+    }
+  }
+}
+
+extern "C" int sa_ew_ntiles(int L) { return sa_div_up(L, SA_EW_ROWS); }
+
+template <bool APPLY>
+static int launch_ew(int dtype, int C, const SaEwArgs& a0, hipStream_t st) {
+  SaEwArgs a = a0;
+  a.ntiles = sa_div_up(a.L, SA_EW_ROWS);
+  dim3 grid(a.ntiles, a.B);
+#define SA_EW_CASE(CC)                                                                      \
+  if (C == CC) {                                                                            \
+    if (dtype == SA_BF16) hipLaunchKernelGGL((sa_ew_kernel<bf16_t, CC, APPLY>), grid, dim3(256), 0, st, a); \
+    else hipLaunchKernelGGL((sa_ew_kernel<float, CC, APPLY>), grid, dim3(256), 0, st, a);   \
+    hipError_t e = hipGetLastError();                                                       \
+    return e == hipSuccess ? 0 : -(int)e;                                                   \
+  }
+  SA_EW_CASE(32) SA_EW_CASE(64) SA_EW_CASE(128)
+  return -38;
+}
+
+extern "C" int sa_ew_stats(int dtype, int C, const SaEwArgs* a, void* stream) {
+  if (!a || !a->g || !a->x || a->B <= 0 || a->L <= 0) return -22;
+  return launch_ew<false>(dtype, C, *a, reinterpret_cast<hipStream_t>(stream));
+}
+extern "C" int sa_ew_apply(int dtype, int C, const SaEwArgs* a, void* stream) {
+  if (!a || !a->g || !a->x || !a->out || a->B <= 0 || a->L <= 0) return -22;
+  return launch_ew<true>(dtype, C, *a, reinterpret_cast<hipStream_t>(stream));
+}
+
+// ---------------------------------------------------------------------------------
+// transform_stats: per-(b,c) sum / sumsq of swish(x*s1+t1) -- statistics of the encoder
+// output for the classifier's first BatchNorm (`norm`, ConvAutoEncoder.py:44,59).
+// ---------------------------------------------------------------------------------
+template <typename T, int C>
+__global__ __launch_bounds__(256) void sa_act_stats_kernel(const T* __restrict__ x,
+                                                           const float* __restrict__ s1p,
+                                                           const float* __restrict__ t1p,
+                                                           int swish, float* __restrict__ stats,
+                                                           int L, int ntiles) {
+  typedef Tr<T> tr;
+  constexpr int VEC = tr::VEC, CH = C / VEC, RPP = 256 / CH;
+  __shared__ float red[RPP][C][2];
+  const int tid = threadIdx.x, b = blockIdx.y, tile = blockIdx.x;
+  const int c = tid % CH, r0 = tid / CH;
+  float s1[VEC], t1[VEC], a0[VEC], a1[VEC];
+#pragma unroll
+  for (int j = 0; j < VEC; ++j) {
+    s1[j] = s1p ? s1p[(size_t)b * C + c * VEC + j] : 1.0f;
+    t1[j] = t1p ? t1p[(size_t)b * C + c * VEC + j] : 0.0f;
+    a0[j] = 0.f; a1[j] = 0.f;
+  }
+  const T* xp = x + (size_t)b * L * C + c * VEC;
+  for (int r = r0; r < SA_EW_ROWS; r += RPP) {
+    const int l = tile * SA_EW_ROWS + r;
+    if (l >= L) break;
+    float f[VEC];
+    tr::unpack(*reinterpret_cast<const uint4*>(xp + (size_t)l * C), f);
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) {
+      float v = fmaf(f[j], s1[j], t1[j]);
+      if (swish) v = sa_swish(v);
+      a0[j] += v; a1[j] = fmaf(v, v, a1[j]);
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < VEC; ++j) { red[r0][c * VEC + j][0] = a0[j]; red[r0][c * VEC + j][1] = a1[j]; }
+  __syncthreads();
+  if (tid < C) {
+    float s = 0.f, q = 0.f;
+    for (int r = 0; r < RPP; ++r) { s += red[r][tid][0]; q += red[r][tid][1]; }
+    float* d = stats + (((size_t)b * ntiles + tile) * C + tid) * 2;
+    d[0] = s; d[1] = q;
+  }
+}
+
+extern "C" int sa_act_stats(int dtype, int C, const void* x, const float* s1, const float* t1,
+                            int swish, float* stats, int B, int L, void* stream) {
+  if (!x || !stats || B <= 0 || L <= 0) return -22;
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  const int nt = sa_div_up(L, SA_EW_ROWS);
+  dim3 grid(nt, B);
+  if (C == 128 && dtype == SA_BF16)
+    hipLaunchKernelGGL((sa_act_stats_kernel<bf16_t, 128>), grid, dim3(256), 0, st,
+                       reinterpret_cast<const bf16_t*>(x), s1, t1, swish, stats, L, nt);
+  else if (C == 128)
+    hipLaunchKernelGGL((sa_act_stats_kernel<float, 128>), grid, dim3(256), 0, st,
+                       reinterpret_cast<const float*>(x), s1, t1, swish, stats, L, nt);
+  else
+    return -38;
+  hipError_t e = hipGetLastError();
+  return e == hipSuccess ? 0 : -(int)e;
+}
+
+// ---------------------------------------------------------------------------------
+// batched slab sum: dst[bb][i] = sum_k slabs[bb][k][i]   (fixed order, double accumulate)
+// ---------------------------------------------------------------------------------
+__global__ void sa_sum_partials_kernel(const float* __restrict__ slabs, float* __restrict__ dst,
+                                       int nslab, int n) {
+  const int bb = blockIdx.y;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+    double s = 0.0;
+    const float* p = slabs + (size_t)bb * nslab * n + i;
+    for (int k = 0; k < nslab; ++k) s += (double)p[(size_t)k * n];
+    dst[(size_t)bb * n + i] = (float)s;
+  }
+}
+
+extern "C" int sa_sum_partials(const float* slabs, float* dst, int nbatch, int nslab, int n,
+                               void* stream) {
+  if (!slabs || !dst || nbatch <= 0 || nslab <= 0 || n <= 0) return -22;
+  hipLaunchKernelGGL(sa_sum_partials_kernel, dim3(sa_div_up(n, 256), nbatch), dim3(256), 0,
+                     reinterpret_cast<hipStream_t>(stream), slabs, dst, nslab, n);
+  hipError_t e = hipGetLastError();
+  return e == hipSuccess ? 0 : -(int)e;
+}
+
+// ---------------------------------------------------------------------------------
+// finalisers.  sums layouts: IN  [B][C][2],  BN  [C][2]  (sum, sumsq) or (S1, S2).
+// ---------------------------------------------------------------------------------
+// InstanceNorm forward: mean, rstd, scale = gamma*rstd, shift = beta - mean*scale per (b,c)
+__global__ void sa_fin_in_fwd_kernel(const float* __restrict__ sums, int BC, int C, float n,
+                                     const float* __restrict__ gamma, const float* __restrict__ beta,
+                                     float eps, float* mean, float* rstd, float* scale, float* shift) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= BC) return;
+  const double m = (double)sums[2 * i] / n;
+  double var = (double)sums[2 * i + 1] / n - m * m;
+  if (var < 0.0) var = 0.0;
+  const float r = (float)(1.0 / sqrt(var + (double)eps));
+  const float sc = gamma[i % C] * r;
+  mean[i] = (float)m; rstd[i] = r; scale[i] = sc; shift[i] = beta[i % C] - (float)m * sc;
+}
+
+extern "C" int sa_fin_in_fwd(const float* sums, int B, int C, int n, const float* gamma,
+                             const float* beta, float eps, float* mean, float* rstd, float* scale,
+                             float* shift, void* stream) {
+  if (!sums || !gamma || !beta || !mean || !rstd || !scale || !shift) return -22;
+  hipLaunchKernelGGL(sa_fin_in_fwd_kernel, dim3(sa_div_up(B * C, 256)), dim3(256), 0,
+                     reinterpret_cast<hipStream_t>(stream), sums, B * C, C, (float)n, gamma, beta,
+                     eps, mean, rstd, scale, shift);
+  hipError_t e = hipGetLastError();
+  return e == hipSuccess ? 0 : -(int)e;
+}
+
+// BatchNorm (train mode) forward from (possibly all-reduced) sums over `count` elements per
+// channel; updates running_mean / running_var (unbiased) with `momentum` like nn.BatchNorm1d.
+__global__ void sa_fin_bn_fwd_kernel(const float* __restrict__ sums, int C, double count,
+                                     const float* __restrict__ gamma, const float* __restrict__ beta,
+                                     float eps, float momentum, float* run_mean, float* run_var,
+                                     float* mean, float* rstd, float* scale, float* shift) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= C) return;
+  const double m = (double)sums[2 * i] / count;
+  double var = (double)sums[2 * i + 1] / count - m * m;
+  if (var < 0.0) var = 0.0;
+  const float r = (float)(1.0 / sqrt(var + (double)eps));
+  const float sc = gamma[i] * r;
+  mean[i] = (float)m; rstd[i] = r; scale[i] = sc; shift[i] = beta[i] - (float)m * sc;
+  if (run_mean) {
+    const double unb = count > 1.0 ? var * count / (count - 1.0) : var;
+    run_mean[i] = (1.0f - momentum) * run_mean[i] + momentum * (float)m;
+    run_var[i] = (1.0f - momentum) * run_var[i] + momentum * (float)unb;
+  }
+}
+
+extern "C" int sa_fin_bn_fwd(const float* sums, int C, double count, const float* gamma,
+                             const float* beta, float eps, float momentum, float* run_mean,
+                             float* run_var, float* mean, float* rstd, float* scale, float* shift,
+                             void* stream) {
+  if (!sums || !gamma || !beta || !mean || !rstd || !scale || !shift || count <= 0) return -22;
+  hipLaunchKernelGGL(sa_fin_bn_fwd_kernel, dim3(sa_div_up(C, 128)), dim3(128), 0,
+                     reinterpret_cast<hipStream_t>(stream), sums, C, count, gamma, beta, eps,
+                     momentum, run_mean, run_var, mean, rstd, scale, shift);
+  hipError_t e = hipGetLastError();
+  return e == hipSuccess ? 0 : -(int)e;
+}
+
+// Normalisation backward coefficients.  sums = (S1 = sum g', S2 = sum g'*xhat) per group;
+// groups = B*C (InstanceNorm, n = L) or C (BatchNorm, n = count).
+//   d x = c1*g' + c2*xv + c3,  c1 = gamma*rstd, c2 = -c1*rstd*S2/n, c3 = c1*(-S1/n + mean*rstd*S2/n)
+// sign = -1 folds the GradReverse layer in.  lsums (local sums, may equal sums) feed
+// d gamma = sum_b S2, d beta = sum_b S1 (written, not accumulated, when dgamma != null).
+__global__ void sa_fin_norm_bwd_kernel(const float* __restrict__ sums, const float* __restrict__ lsums,
+                                       int G, int C, double n, const float* __restrict__ gamma,
+                                       const float* __restrict__ mean, const float* __restrict__ rstd,
+                                       float sign, float* c1, float* c2, float* c3, float* dgamma,
+                                       float* dbeta, int nb) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < G) {
+    const double S1 = sums[2 * i], S2 = sums[2 * i + 1];
+    const double r = rstd[i], m = mean[i];
+    const double k1 = (double)gamma[i % C] * r;
+    c1[i] = sign * (float)k1;
+    c2[i] = sign * (float)(-k1 * r * S2 / n);
+    c3[i] = sign * (float)(k1 * (-S1 / n + m * r * S2 / n));
+  }
+  if (dgamma && i < C) {
+    double a = 0.0, bsum = 0.0;
+    for (int b = 0; b < nb; ++b) { bsum += lsums[2 * ((size_t)b * C + i)]; a += lsums[2 * ((size_t)b * C + i) + 1]; }
+    dgamma[i] = (float)a; dbeta[i] = (float)bsum;
+  }
+}
+
+extern "C" int sa_fin_norm_bwd(const float* sums, const float* lsums, int groups, int C, double n,
+                               const float* gamma, const float* mean, const float* rstd, float sign,
+                               float* c1, float* c2, float* c3, float* dgamma, float* dbeta,
+                               void* stream) {
+  if (!sums || !gamma || !mean || !rstd || !c1 || !c2 || !c3 || groups % C) return -22;
+  const int tot = groups > C ? groups : C;
+  hipLaunchKernelGGL(sa_fin_norm_bwd_kernel, dim3(sa_div_up(tot, 256)), dim3(256), 0,
+                     reinterpret_cast<hipStream_t>(stream), sums, lsums ? lsums : sums, groups, C,
+                     n, gamma, mean, rstd, sign, c1, c2, c3, dgamma, dbeta, groups / C);
+  hipError_t e = hipGetLastError();
+  return e == hipSuccess ? 0 : -(int)e;
+}
+
+// bias gradient from per-(b,c) sums: db[c] = sum_b sums[b][c][0]
+__global__ void sa_fin_bias_kernel(const float* __restrict__ sums, int B, int C, float* db) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= C) return;
+  double s = 0.0;
+  for (int b = 0; b < B; ++b) s += sums[2 * ((size_t)b * C + i)];
+  db[i] = (float)s;
+}
+
+extern "C" int sa_fin_bias(const float* sums, int B, int C, float* db, void* stream) {
+  if (!sums || !db) return -22;
+  hipLaunchKernelGGL(sa_fin_bias_kernel, dim3(sa_div_up(C, 128)), dim3(128), 0,
+                     reinterpret_cast<hipStream_t>(stream), sums, B, C, db);
+  hipError_t e = hipGetLastError();
+  return e == hipSuccess ? 0 : -(int)e;
+}

@@ -1,0 +1,471 @@
+// Classifier head: statistics pooling with the reference's reshape quirk, the dense FC head
+// on f32 MFMA, log-softmax, and the loss reductions with fused gradients.
+//
+// Reference: models/ConvAutoEncoder.py:57-69 (TDNNSexClassifier.forward: reshape at :61 is a
+// MEMORY REINTERPRETATION of the [B,128,L'] tensor as [B,L',128], then speechbrain
+// StatisticsPooling mean/std over dim 1), :47-55 (classify), speechbrain_convae_train.py:105-108
+// (recon / NLL / confusion losses), utils/cosine_similarity_loss.py:53-56.
+#include "sa_common.h"
+
+// ---------------------------------------------------------------------------------
+// Statistics pooling.  The classifier's last BatchNorm output, in the reference's channel-
+// major memory order, has flat index f = c*L + l; the reshape regroups it so that pooled
+// column j collects every f with f % 128 == j.  Here the tensor is channels-last [B][L][128]
+// (stored ReLU output r, BN affine applied on the fly), so element (l, c) belongs to column
+// j = (c*L + l) % 128.  One workgroup stages a 128-row tile in LDS and each thread sums one
+// column along the wrapped diagonals -> deterministic, coalesced, no atomics.
+// ---------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void sa_pool_fwd_kernel(const T* __restrict__ r,
+                                                          const float* __restrict__ sc,
+                                                          const float* __restrict__ sh,
+                                                          float* __restrict__ part, int L,
+                                                          int ntiles) {
+  constexpr int C = 128, VEC = Tr<T>::VEC, CH = C / VEC, RPP = 256 / CH, PITCH = 129;
+  __shared__ float ts[128 * PITCH];
+  __shared__ float half[128][2];
+  const int tid = threadIdx.x, b = blockIdx.y, tile = blockIdx.x, l0 = tile * 128;
+  {
+    const int c = tid % CH, r0 = tid / CH;
+    float s[VEC], t[VEC];
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) { s[j] = sc[c * VEC + j]; t[j] = sh[c * VEC + j]; }
+    for (int rr = r0; rr < 128; rr += RPP) {
+      const int l = l0 + rr;
+      float f[VEC];
+#pragma unroll
+      for (int j = 0; j < VEC; ++j) f[j] = 0.0f;
+      if (l < L) {
+        Tr<T>::unpack(*reinterpret_cast<const uint4*>(r + ((size_t)b * L + l) * C + c * VEC), f);
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) f[j] = fmaf(f[j], s[j], t[j]);
+      }
+#pragma unroll
+      for (int j = 0; j < VEC; ++j) ts[rr * PITCH + c * VEC + j] = f[j];
+    }
+  }
+  __syncthreads();
+  const int j = tid & 127, hsel = tid >> 7;
+  float s = 0.0f, q = 0.0f;
+  const int Lm = L % 128, l0m = l0 % 128;
+  for (int c = hsel * 64; c < hsel * 64 + 64; ++c) {
+    const int rr = ((j - (c * Lm) % 128 - l0m) % 128 + 256) % 128;
+    if (l0 + rr < L) {
+      const float v = ts[rr * PITCH + c];
+      s += v; q = fmaf(v, v, q);
+    }
+  }
+  if (hsel == 1) { half[j][0] = s; half[j][1] = q; }
+  __syncthreads();
+  if (hsel == 0) {
+    float* d = part + (((size_t)b * ntiles + tile) * 128 + j) * 2;
+    d[0] = s + half[j][0]; d[1] = q + half[j][1];
+  }
+}
+
+extern "C" int sa_pool_ntiles(int L) { return sa_div_up(L, 128); }
+
+extern "C" int sa_pool_fwd(int dtype, const void* r, const float* scale, const float* shift,
+                           float* part, int B, int L, void* stream) {
+  if (!r || !scale || !shift || !part || B <= 0 || L <= 1) return -22;
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  const int nt = sa_div_up(L, 128);
+  dim3 grid(nt, B);
+  if (dtype == SA_BF16)
+    hipLaunchKernelGGL(sa_pool_fwd_kernel<bf16_t>, grid, dim3(256), 0, st,
+                       reinterpret_cast<const bf16_t*>(r), scale, shift, part, L, nt);
+  else
+    hipLaunchKernelGGL(sa_pool_fwd_kernel<float>, grid, dim3(256), 0, st,
+                       reinterpret_cast<const float*>(r), scale, shift, part, L, nt);
+  hipError_t e = hipGetLastError();
+  return e == hipSuccess ? 0 : -(int)e;
+}
+
+// sums [B][128][2] -> pooled [B][256] = (mean + eps*((1-9)*noise+9) if noise, std_unbiased + eps)
+// and saves mean / raw std for the backward.
+__global__ void sa_pool_fin_kernel(const float* __restrict__ sums, int B, int n,
+                                   const float* __restrict__ noise, float eps, float* pooled,
+                                   float* mean, float* stdraw) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= B * 128) return;
+  const int b = i / 128, j = i % 128;
+  const double S = sums[2 * i], Q = sums[2 * i + 1];
+  const double m = S / n;
+  double var = (Q - S * m) / (n - 1);
+  if (var < 0.0) var = 0.0;
+  const float sd = (float)sqrt(var);
+  mean[i] = (float)m; stdraw[i] = sd;
+  float mo = (float)m;
+  if (noise) mo += eps * ((1.0f - 9.0f) * noise[i] + 9.0f);
+  pooled[(size_t)b * 256 + j] = mo;
+  pooled[(size_t)b * 256 + 128 + j] = sd + eps;
+}
+
+extern "C" int sa_pool_fin(const float* sums, int B, int n, const float* noise, float eps,
+                           float* pooled, float* mean, float* stdraw, void* stream) {
+  if (!sums || !pooled || !mean || !stdraw || n < 2) return -22;
+  hipLaunchKernelGGL(sa_pool_fin_kernel, dim3(sa_div_up(B * 128, 256)), dim3(256), 0,
+                     reinterpret_cast<hipStream_t>(stream), sums, B, n, noise, eps, pooled, mean,
+                     stdraw);
+  hipError_t e = hipGetLastError();
+  return e == hipSuccess ? 0 : -(int)e;
+}
+
+// Pooling backward: g[b][l][c] = dmean_j/n + dstd_j * (xbn - mean_j) / ((n-1) * std_j),
+// j = (c*L + l) % 128, xbn = r*scale[c] + shift[c].   dpooled [B][256].
+template <typename T>
+__global__ __launch_bounds__(256) void sa_pool_bwd_kernel(const T* __restrict__ r,
+                                                          const float* __restrict__ sc,
+                                                          const float* __restrict__ sh,
+                                                          const float* __restrict__ dpooled,
+                                                          const float* __restrict__ mean,
+                                                          const float* __restrict__ stdraw,
+                                                          T* __restrict__ g, int L) {
+  constexpr int C = 128, VEC = Tr<T>::VEC, CH = C / VEC, RPP = 256 / CH;
+  __shared__ float ka[128], kb[128];
+  const int tid = threadIdx.x, b = blockIdx.y, l0 = blockIdx.x * SA_WAVE * 4;
+  if (tid < 128) {
+    const float dm = dpooled[(size_t)b * 256 + tid], ds = dpooled[(size_t)b * 256 + 128 + tid];
+    const float sd = stdraw[(size_t)b * 128 + tid], m = mean[(size_t)b * 128 + tid];
+    const float inv = sd > 0.0f ? 1.0f / ((float)(L - 1) * sd) : 0.0f;
+    kb[tid] = ds * inv;
+    ka[tid] = dm / (float)L - ds * inv * m;
+  }
+  __syncthreads();
+  const int c = tid % CH, r0 = tid / CH;
+  float s[VEC], t[VEC];
+  int jb[VEC];
+#pragma unroll
+  for (int j = 0; j < VEC; ++j) {
+    s[j] = sc[c * VEC + j]; t[j] = sh[c * VEC + j];
+    jb[j] = (int)(((long long)(c * VEC + j) * L) % 128);
+  }
+  for (int rr = r0; rr < 256; rr += RPP) {
+    const int l = l0 + rr;
+    if (l >= L) break;
+    float f[VEC];
+    Tr<T>::unpack(*reinterpret_cast<const uint4*>(r + ((size_t)b * L + l) * C + c * VEC), f);
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) {
+      const int col = (jb[j] + l) % 128;
+      f[j] = fmaf(kb[col], fmaf(f[j], s[j], t[j]), ka[col]);
+    }
+    *reinterpret_cast<uint4*>(g + ((size_t)b * L + l) * C + c * VEC) = Tr<T>::pack(f);
+  }
+}
+
+extern "C" int sa_pool_bwd(int dtype, const void* r, const float* scale, const float* shift,
+                           const float* dpooled, const float* mean, const float* stdraw, void* g,
+                           int B, int L, void* stream) {
+  if (!r || !scale || !shift || !dpooled || !mean || !stdraw || !g || L < 2) return -22;
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  dim3 grid(sa_div_up(L, 256), B);
+  if (dtype == SA_BF16)
+    hipLaunchKernelGGL(sa_pool_bwd_kernel<bf16_t>, grid, dim3(256), 0, st,
+                       reinterpret_cast<const bf16_t*>(r), scale, shift, dpooled, mean, stdraw,
+                       reinterpret_cast<bf16_t*>(g), L);
+  else
+    hipLaunchKernelGGL(sa_pool_bwd_kernel<float>, grid, dim3(256), 0, st,
+                       reinterpret_cast<const float*>(r), scale, shift, dpooled, mean, stdraw,
+                       reinterpret_cast<float*>(g), L);
+  hipError_t e = hipGetLastError();
+  return e == hipSuccess ? 0 : -(int)e;
+}
+
+// ---------------------------------------------------------------------------------
+// Dense layers of the FC head on exact-f32 MFMA (v_mfma_f32_32x32x2_f32).
+//   Y[m][n] = act( sum_k A(m,k) * Bm(k,n) + bias[n] ),   A(m,k) = P(X[m*lda + k])
+//   P(v) = (v*ps[k] + pt[k]) (BatchNorm of the previous layer folded in), Bm(k,n) = W[k*sbk + n*sbn]
+// One wave per 32x32 output tile; rows >= M / cols >= N are masked.
+// ---------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void sa_dense_kernel(const float* __restrict__ X, int lda,
+                                                      const float* __restrict__ ps,
+                                                      const float* __restrict__ pt,
+                                                      const float* __restrict__ W, int sbk, int sbn,
+                                                      const float* __restrict__ bias, float* __restrict__ Y,
+                                                      int ldy, int M, int N, int K, int relu) {
+  const int lane = threadIdx.x, n0 = blockIdx.x * 32, m0 = blockIdx.y * 32;
+  const int m = m0 + (lane & 31), n = n0 + (lane & 31), kh = lane >> 5;
+  f32x16 acc;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) acc[i] = 0.0f;
+  for (int k0 = 0; k0 < K; k0 += 2) {
+    const int k = k0 + kh;
+    float av = 0.0f, bv = 0.0f;
+    if (k < K) {
+      if (m < M) {
+        av = X[(size_t)m * lda + k];
+        if (ps) av = fmaf(av, ps[k], pt[k]);
+      }
+      if (n < N) bv = W[(size_t)k * sbk + (size_t)n * sbn];
+    }
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc, 0, 0, 0);
+  }
+  if (n < N) {
+    const float bb = bias ? bias[n] : 0.0f;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const int mr = m0 + sa_acc_row(i, lane);
+      if (mr < M) {
+        float v = acc[i] + bb;
+        if (relu) v = fmaxf(v, 0.0f);
+        Y[(size_t)mr * ldy + n] = v;
+      }
+    }
+  }
+}
+
+extern "C" int sa_dense(const float* X, int lda, const float* ps, const float* pt, const float* W,
+                        int sbk, int sbn, const float* bias, float* Y, int ldy, int M, int N, int K,
+                        int relu, void* stream) {
+  if (!X || !W || !Y || M <= 0 || N <= 0 || K <= 0) return -22;
+  dim3 grid(sa_div_up(N, 32), sa_div_up(M, 32));
+  hipLaunchKernelGGL(sa_dense_kernel, grid, dim3(64), 0, reinterpret_cast<hipStream_t>(stream), X,
+                     lda, ps, pt, W, sbk, sbn, bias, Y, ldy, M, N, K, relu);
+  hipError_t e = hipGetLastError();
+  return e == hipSuccess ? 0 : -(int)e;
+}
+
+// column sums of a small [M][N] matrix: sums[n][0] = sum_m X, sums[n][1] = sum_m X*Xh
+// where Xh = X (sumsq, Xh null) or a second matrix (e.g. normalised activations).
+__global__ void sa_colsums_kernel(const float* __restrict__ X, const float* __restrict__ H,
+                                  const float* __restrict__ hm, const float* __restrict__ hr,
+                                  int M, int N, float* sums) {
+  const int n = blockIdx.x * blockDim.x + threadIdx.x;
+  if (n >= N) return;
+  double s = 0.0, q = 0.0;
+  for (int m = 0; m < M; ++m) {
+    const float x = X[(size_t)m * N + n];
+    float h = H ? H[(size_t)m * N + n] : x;
+    if (hm) h = (h - hm[n]) * hr[n];
+    s += x; q += (double)x * h;
+  }
+  sums[2 * n] = (float)s; sums[2 * n + 1] = (float)q;
+}
+
+extern "C" int sa_colsums(const float* X, const float* H, const float* hmean, const float* hrstd,
+                          int M, int N, float* sums, void* stream) {
+  if (!X || !sums) return -22;
+  hipLaunchKernelGGL(sa_colsums_kernel, dim3(sa_div_up(N, 64)), dim3(64), 0,
+                     reinterpret_cast<hipStream_t>(stream), X, H, hmean, hrstd, M, N, sums);
+  hipError_t e = hipGetLastError();
+  return e == hipSuccess ? 0 : -(int)e;
+}
+
+// BatchNorm backward on a small [M][N] activation (batch statistics over `count` rows,
+// possibly global): dH = gamma*rstd*(G - S1/count - hhat*S2/count) [* (H > 0)]
+__global__ void sa_bn2d_bwd_kernel(const float* __restrict__ G, const float* __restrict__ H,
+                                   const float* __restrict__ sums, double count,
+                                   const float* __restrict__ gamma, const float* __restrict__ mean,
+                                   const float* __restrict__ rstd, int relu_mask, int M, int N,
+                                   float* dH) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= M * N) return;
+  const int n = i % N;
+  const float hh = (H[i] - mean[n]) * rstd[n];
+  float v = gamma[n] * rstd[n] * (G[i] - (float)(sums[2 * n] / count) - hh * (float)(sums[2 * n + 1] / count));
+  if (relu_mask && !(H[i] > 0.0f)) v = 0.0f;
+  dH[i] = v;
+}
+
+extern "C" int sa_bn2d_bwd(const float* G, const float* H, const float* sums, double count,
+                           const float* gamma, const float* mean, const float* rstd, int relu_mask,
+                           int M, int N, float* dH, void* stream) {
+  if (!G || !H || !sums || !gamma || !mean || !rstd || !dH) return -22;
+  hipLaunchKernelGGL(sa_bn2d_bwd_kernel, dim3(sa_div_up(M * N, 256)), dim3(256), 0,
+                     reinterpret_cast<hipStream_t>(stream), G, H, sums, count, gamma, mean, rstd,
+                     relu_mask, M, N, dH);
+  hipError_t e = hipGetLastError();
+  return e == hipSuccess ? 0 : -(int)e;
+}
+
+// dW[n][k] = sum_m dY[m][n] * P(X[m][k])  (P = BatchNorm affine of the layer input)
+__global__ void sa_dense_wgrad_kernel(const float* __restrict__ dY, const float* __restrict__ X,
+                                      const float* __restrict__ ps, const float* __restrict__ pt,
+                                      int M, int N, int K, float* dW) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= N * K) return;
+  const int n = i / K, k = i % K;
+  float s = 0.0f;
+  for (int m = 0; m < M; ++m) {
+    float x = X[(size_t)m * K + k];
+    if (ps) x = fmaf(x, ps[k], pt[k]);
+    s = fmaf(dY[(size_t)m * N + n], x, s);
+  }
+  dW[i] = s;
+}
+
+extern "C" int sa_dense_wgrad(const float* dY, const float* X, const float* ps, const float* pt,
+                              int M, int N, int K, float* dW, void* stream) {
+  if (!dY || !X || !dW) return -22;
+  hipLaunchKernelGGL(sa_dense_wgrad_kernel, dim3(sa_div_up(N * K, 256)), dim3(256), 0,
+                     reinterpret_cast<hipStream_t>(stream), dY, X, ps, pt, M, N, K, dW);
+  hipError_t e = hipGetLastError();
+  return e == hipSuccess ? 0 : -(int)e;
+}
+
+// log_softmax over the last dim of [M][N] (N small), and its backward
+__global__ void sa_log_softmax_kernel(const float* __restrict__ X, float* __restrict__ Y, int M, int N) {
+  const int m = blockIdx.x * blockDim.x + threadIdx.x;
+  if (m >= M) return;
+  float mx = -INFINITY;
+  for (int n = 0; n < N; ++n) mx = fmaxf(mx, X[(size_t)m * N + n]);
+  float s = 0.0f;
+  for (int n = 0; n < N; ++n) s += expf(X[(size_t)m * N + n] - mx);
+  const float lse = mx + logf(s);
+  for (int n = 0; n < N; ++n) Y[(size_t)m * N + n] = X[(size_t)m * N + n] - lse;
+}
+__global__ void sa_log_softmax_bwd_kernel(const float* __restrict__ dY, const float* __restrict__ Y,
+                                          float* __restrict__ dX, int M, int N) {
+  const int m = blockIdx.x * blockDim.x + threadIdx.x;
+  if (m >= M) return;
+  float s = 0.0f;
+  for (int n = 0; n < N; ++n) s += dY[(size_t)m * N + n];
+  for (int n = 0; n < N; ++n) dX[(size_t)m * N + n] = dY[(size_t)m * N + n] - expf(Y[(size_t)m * N + n]) * s;
+}
+extern "C" int sa_log_softmax(const float* X, float* Y, int M, int N, void* stream) {
+  if (!X || !Y) return -22;
+  hipLaunchKernelGGL(sa_log_softmax_kernel, dim3(sa_div_up(M, 64)), dim3(64), 0,
+                     reinterpret_cast<hipStream_t>(stream), X, Y, M, N);
+  hipError_t e = hipGetLastError();
+  return e == hipSuccess ? 0 : -(int)e;
+}
+extern "C" int sa_log_softmax_bwd(const float* dY, const float* Y, float* dX, int M, int N, void* stream) {
+  if (!dY || !Y || !dX) return -22;
+  hipLaunchKernelGGL(sa_log_softmax_bwd_kernel, dim3(sa_div_up(M, 64)), dim3(64), 0,
+                     reinterpret_cast<hipStream_t>(stream), dY, Y, dX, M, N);
+  hipError_t e = hipGetLastError();
+  return e == hipSuccess ? 0 : -(int)e;
+}
+
+// ---------------------------------------------------------------------------------
+// Loss reductions with fused gradients.
+// ---------------------------------------------------------------------------------
+// recon loss: mean over N of |a-b| (kind 0, nn.L1Loss) or (a-b)^2 (kind 1, nn.MSELoss);
+// grad[i] = d loss / d a[i].  Two-level deterministic reduction: part[block] then one thread.
+__global__ __launch_bounds__(256) void sa_recon_loss_kernel(const float* __restrict__ a,
+                                                            const float* __restrict__ b, size_t n,
+                                                            int kind, float* __restrict__ grad,
+                                                            double* __restrict__ part) {
+  __shared__ double wsum[4];
+  const float inv = 1.0f / (float)n;
+  double s = 0.0;
+  const size_t n4 = n / 4;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
+    const float4 x = reinterpret_cast<const float4*>(a)[i], y = reinterpret_cast<const float4*>(b)[i];
+    float d[4] = {x.x - y.x, x.y - y.y, x.z - y.z, x.w - y.w}, g[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      if (kind == 0) { s += fabsf(d[j]); g[j] = d[j] > 0.f ? inv : (d[j] < 0.f ? -inv : 0.f); }
+      else { s += (double)d[j] * d[j]; g[j] = 2.0f * d[j] * inv; }
+    }
+    if (grad) reinterpret_cast<float4*>(grad)[i] = make_float4(g[0], g[1], g[2], g[3]);
+  }
+  if (blockIdx.x == 0 && threadIdx.x == 0)
+    for (size_t i = n4 * 4; i < n; ++i) {
+      const float d = a[i] - b[i];
+      if (kind == 0) { s += fabsf(d); if (grad) grad[i] = d > 0.f ? inv : (d < 0.f ? -inv : 0.f); }
+      else { s += (double)d * d; if (grad) grad[i] = 2.0f * d * inv; }
+    }
+  s = sa_wave_sum_d(s);
+  if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) part[blockIdx.x] = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+}
+__global__ void sa_recon_loss_fin_kernel(const double* part, int nb, double n, float* loss) {
+  double s = 0.0;
+  for (int i = 0; i < nb; ++i) s += part[i];
+  loss[0] = (float)(s / n);
+}
+#define SA_LOSS_BLOCKS 512
+extern "C" int sa_loss_workspace_bytes() { return SA_LOSS_BLOCKS * (int)sizeof(double); }
+extern "C" int sa_recon_loss(const float* a, const float* b, long long n, int kind, float* grad,
+                             float* loss, void* workspace, void* stream) {
+  if (!a || !b || !loss || !workspace || n <= 0) return -22;
+  if ((reinterpret_cast<uintptr_t>(a) | reinterpret_cast<uintptr_t>(b) |
+       reinterpret_cast<uintptr_t>(grad)) & 15) return -22;
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  int nb = (int)((n / 4 + 255) / 256);
+  if (nb < 1) nb = 1;
+  if (nb > SA_LOSS_BLOCKS) nb = SA_LOSS_BLOCKS;
+  hipLaunchKernelGGL(sa_recon_loss_kernel, dim3(nb), dim3(256), 0, st, a, b, (size_t)n, kind, grad,
+                     reinterpret_cast<double*>(workspace));
+  hipLaunchKernelGGL(sa_recon_loss_fin_kernel, dim3(1), dim3(1), 0, st,
+                     reinterpret_cast<const double*>(workspace), nb, (double)n, loss);
+  hipError_t e = hipGetLastError();
+  return e == hipSuccess ? 0 : -(int)e;
+}
+
+// NLLLoss(mean) and the confusion MSE against log(0.5) = -0.6931 (the reference's literal,
+// speechbrain_convae_train.py:107-108) on logp [B][2]; out = (nll, conf); grads per element.
+__global__ void sa_cls_losses_kernel(const float* __restrict__ logp, const long long* __restrict__ label,
+                                     int B, int NC, float* out, float* dnll, float* dconf) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  double nll = 0.0, conf = 0.0;
+  for (int b = 0; b < B; ++b)
+    for (int c = 0; c < NC; ++c) {
+      const float lp = logp[b * NC + c];
+      const float d = lp - (-0.6931f);
+      conf += (double)d * d;
+      if (dconf) dconf[b * NC + c] = 2.0f * d / (float)(B * NC);
+      const bool hit = (long long)c == label[b];
+      if (hit) nll -= lp;
+      if (dnll) dnll[b * NC + c] = hit ? -1.0f / (float)B : 0.0f;
+    }
+  out[0] = (float)(nll / B);
+  out[1] = (float)(conf / (B * NC));
+}
+extern "C" int sa_cls_losses(const float* logp, const long long* label, int B, int NC, float* out,
+                             float* dnll, float* dconf, void* stream) {
+  if (!logp || !label || !out) return -22;
+  hipLaunchKernelGGL(sa_cls_losses_kernel, dim3(1), dim3(64), 0,
+                     reinterpret_cast<hipStream_t>(stream), logp, label, B, NC, out, dnll, dconf);
+  hipError_t e = hipGetLastError();
+  return e == hipSuccess ? 0 : -(int)e;
+}
+
+// CosineSimilarityLoss (utils/cosine_similarity_loss.py:53-56):
+//   loss = sum_{b,s} (1 - cos(x1[b,s,:], x2[b,s,:]; eps 1e-6)) / S.     One wave per (b,s) row.
+// torch.cosine_similarity: dot / max(|x1|*|x2|, eps)  [ATen: (x1.x2) / sqrt(max(|x1|^2*|x2|^2, eps^2))]
+// dx1 (optional) = d loss / d x1 = -(1/S) * (x2/(|x1||x2|) - cos * x1/|x1|^2)
+__global__ __launch_bounds__(256) void sa_cosine_rows_kernel(const float* __restrict__ x1,
+                                                             const float* __restrict__ x2,
+                                                             int rows, int D, int S, float eps,
+                                                             float* __restrict__ rowloss,
+                                                             float* __restrict__ dx1) {
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (row >= rows) return;
+  const float* a = x1 + (size_t)row * D;
+  const float* b = x2 + (size_t)row * D;
+  float dot = 0.f, na = 0.f, nb = 0.f;
+  for (int i = lane; i < D; i += 64) { dot = fmaf(a[i], b[i], dot); na = fmaf(a[i], a[i], na); nb = fmaf(b[i], b[i], nb); }
+  dot = sa_wave_sum(dot); na = sa_wave_sum(na); nb = sa_wave_sum(nb);
+  const float den2 = fmaxf(na * nb, eps * eps);
+  const float cs = dot / sqrtf(den2);
+  if (lane == 0) rowloss[row] = 1.0f - cs;
+  if (dx1) {
+    const bool clamped = na * nb < eps * eps;
+    const float inv = 1.0f / sqrtf(den2), k = -1.0f / (float)S;
+    for (int i = lane; i < D; i += 64) {
+      float g = b[i] * inv;
+      if (!clamped) g -= cs * a[i] / na;
+      dx1[(size_t)row * D + i] = k * g;
+    }
+  }
+}
+__global__ void sa_cosine_fin_kernel(const float* rowloss, int rows, int S, float* loss) {
+  double s = 0.0;
+  for (int i = 0; i < rows; ++i) s += rowloss[i];
+  loss[0] = (float)(s / S);
+}
+extern "C" int sa_cosine_loss(const float* x1, const float* x2, int B, int S, int D, float* rowloss,
+                              float* loss, float* dx1, void* stream) {
+  if (!x1 || !x2 || !rowloss || !loss || B <= 0 || S <= 0 || D <= 0) return -22;
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  const int rows = B * S;
+  hipLaunchKernelGGL(sa_cosine_rows_kernel, dim3(sa_div_up(rows, 4)), dim3(256), 0, st, x1, x2, rows,
+                     D, S, 1e-6f, rowloss, dx1);
+  hipLaunchKernelGGL(sa_cosine_fin_kernel, dim3(1), dim3(1), 0, st, rowloss, rows, S, loss);
+  hipError_t e = hipGetLastError();
+  return e == hipSuccess ? 0 : -(int)e;
+}

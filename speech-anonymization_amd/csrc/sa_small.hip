@@ -1,0 +1,273 @@
+// The two single-channel ends of the ConvAutoencoder (HBM-bound, plain VALU + LDS):
+//   encoder.0  Conv1d(1 -> 32, k15, p7)   models/ConvAutoEncoder.py:142
+//   decoder.8  Conv1d(32 -> 1, k15, p7)   models/ConvAutoEncoder.py:171
+// and their gradients.  Algorithmic traffic is 80 -> 2560 (or 2560 -> 80) elements per frame;
+// every element crosses HBM once with 16-byte coalesced accesses.
+#include "sa_common.h"
+
+#define SA_K15 15
+#define SA_C32 32
+
+// y[b][l][c] = bias[c] + sum_k x[b][l+k-7] * w[c][flip ? 14-k : k]      (x, w fp32; y T)
+// Used as encoder.0 forward (flip=0) and as decoder.8 dgrad (x = d recon, flip=1).
+template <typename T>
+__global__ __launch_bounds__(256) void sa_conv1toC_kernel(const float* __restrict__ x,
+                                                          const float* __restrict__ w,
+                                                          const float* __restrict__ bias,
+                                                          T* __restrict__ y, int L, int flip,
+                                                          float* __restrict__ stats, int ntiles) {
+  constexpr int VEC = Tr<T>::VEC, CH = SA_C32 / VEC, PPP = 256 / CH, TILE = 512;
+  __shared__ float xs[TILE + SA_K15 - 1];
+  __shared__ __attribute__((aligned(16))) float ws[SA_K15][SA_C32];
+  __shared__ float red[PPP][SA_C32][2];
+  const int tid = threadIdx.x, b = blockIdx.y, l0 = blockIdx.x * TILE;
+  for (int i = tid; i < TILE + SA_K15 - 1; i += 256) {
+    const int g = l0 + i - 7;
+    xs[i] = (g >= 0 && g < L) ? x[(size_t)b * L + g] : 0.0f;
+  }
+  for (int i = tid; i < SA_K15 * SA_C32; i += 256) {
+    const int k = i / SA_C32, c = i % SA_C32;
+    ws[k][c] = w[c * SA_K15 + (flip ? SA_K15 - 1 - k : k)];
+  }
+  __syncthreads();
+  const int c = tid % CH, p0 = tid / CH;
+  float bv[VEC], ssum[VEC], ssq[VEC];
+#pragma unroll
+  for (int j = 0; j < VEC; ++j) { bv[j] = bias ? bias[c * VEC + j] : 0.0f; ssum[j] = 0.f; ssq[j] = 0.f; }
+  for (int p = p0; p < TILE; p += PPP) {
+    const int l = l0 + p;
+    if (l >= L) break;
+    float acc[VEC];
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) acc[j] = bv[j];
+#pragma unroll
+    for (int k = 0; k < SA_K15; ++k) {
+      const float xv = xs[p + k];
+#pragma unroll
+      for (int j = 0; j < VEC; ++j) acc[j] = fmaf(xv, ws[k][c * VEC + j], acc[j]);
+    }
+    const uint4 u = Tr<T>::pack(acc);
+    *reinterpret_cast<uint4*>(y + ((size_t)b * L + l) * SA_C32 + c * VEC) = u;
+    if (stats) {
+      float f[VEC];
+      Tr<T>::unpack(u, f);
+#pragma unroll
+      for (int j = 0; j < VEC; ++j) { ssum[j] += f[j]; ssq[j] = fmaf(f[j], f[j], ssq[j]); }
+    }
+  }
+  if (stats) {
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) { red[p0][c * VEC + j][0] = ssum[j]; red[p0][c * VEC + j][1] = ssq[j]; }
+    __syncthreads();
+    if (tid < SA_C32) {
+      float s = 0.f, q = 0.f;
+      for (int r = 0; r < PPP; ++r) { s += red[r][tid][0]; q += red[r][tid][1]; }
+      float* d = stats + (((size_t)b * ntiles + blockIdx.x) * SA_C32 + tid) * 2;
+      d[0] = s; d[1] = q;
+    }
+  }
+}
+
+extern "C" int sa_conv1toC_ntiles(int L) { return sa_div_up(L, 512); }
+
+extern "C" int sa_conv1toC(int dtype, const float* x, const float* w, const float* bias, void* y,
+                           int B, int L, int flip, float* stats, void* stream) {
+  if (!x || !w || !y || B <= 0 || L <= 0) return -22;
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  const int nt = sa_div_up(L, 512);
+  dim3 grid(nt, B);
+  if (dtype == SA_BF16)
+    hipLaunchKernelGGL(sa_conv1toC_kernel<bf16_t>, grid, dim3(256), 0, st, x, w, bias,
+                       reinterpret_cast<bf16_t*>(y), L, flip, stats, nt);
+  else
+    hipLaunchKernelGGL(sa_conv1toC_kernel<float>, grid, dim3(256), 0, st, x, w, bias,
+                       reinterpret_cast<float*>(y), L, flip, stats, nt);
+  hipError_t e = hipGetLastError();
+  return e == hipSuccess ? 0 : -(int)e;
+}
+
+// y[b][l] = bias + sum_k sum_c P(x[b][l+k-7][c]) * w[c][k]       (x T, y fp32)
+// P = prologue: v*s1[b][c]+t1[b][c], then x*sigmoid(x) if swish.   decoder.8 forward.
+template <typename T>
+__global__ __launch_bounds__(256) void sa_convCto1_kernel(const T* __restrict__ x,
+                                                          const float* __restrict__ w,
+                                                          const float* __restrict__ bias,
+                                                          float* __restrict__ y, int L,
+                                                          const float* __restrict__ s1,
+                                                          const float* __restrict__ t1, int swish) {
+  constexpr int VEC = Tr<T>::VEC, CH = SA_C32 / VEC, RPP = 256 / CH, TILE = 256, PITCH = 36;
+  __shared__ __attribute__((aligned(16))) float xs[(TILE + SA_K15 - 1) * PITCH];
+  __shared__ __attribute__((aligned(16))) float ws[SA_K15][SA_C32];
+  const int tid = threadIdx.x, b = blockIdx.y, l0 = blockIdx.x * TILE;
+  {
+    const int c = tid % CH, r0 = tid / CH;
+    float sc[VEC], sh[VEC];
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) {
+      sc[j] = s1 ? s1[(size_t)b * SA_C32 + c * VEC + j] : 1.0f;
+      sh[j] = t1 ? t1[(size_t)b * SA_C32 + c * VEC + j] : 0.0f;
+    }
+    for (int r = r0; r < TILE + SA_K15 - 1; r += RPP) {
+      const int g = l0 + r - 7;
+      float f[VEC];
+#pragma unroll
+      for (int j = 0; j < VEC; ++j) f[j] = 0.0f;
+      if (g >= 0 && g < L) {
+        const uint4 u = *reinterpret_cast<const uint4*>(x + ((size_t)b * L + g) * SA_C32 + c * VEC);
+        Tr<T>::unpack(u, f);
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) {
+          float v = fmaf(f[j], sc[j], sh[j]);
+          f[j] = swish ? sa_swish(v) : v;
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < VEC; ++j) xs[r * PITCH + c * VEC + j] = f[j];
+    }
+    for (int i = tid; i < SA_K15 * SA_C32; i += 256) {
+      const int k = i / SA_C32, cc = i % SA_C32;
+      ws[k][cc] = w[cc * SA_K15 + k];
+    }
+  }
+  __syncthreads();
+  const int l = l0 + tid;
+  if (l < L) {
+    float acc = bias ? bias[0] : 0.0f;
+#pragma unroll
+    for (int k = 0; k < SA_K15; ++k) {
+      const float4* xr = reinterpret_cast<const float4*>(&xs[(tid + k) * PITCH]);
+      const float4* wr = reinterpret_cast<const float4*>(&ws[k][0]);
+#pragma unroll
+      for (int q = 0; q < SA_C32 / 4; ++q) {
+        const float4 xv = xr[q], wv = wr[q];
+        acc = fmaf(xv.x, wv.x, acc); acc = fmaf(xv.y, wv.y, acc);
+        acc = fmaf(xv.z, wv.z, acc); acc = fmaf(xv.w, wv.w, acc);
+      }
+    }
+    y[(size_t)b * L + l] = acc;
+  }
+}
+
+extern "C" int sa_convCto1(int dtype, const void* x, const float* w, const float* bias, float* y,
+                           int B, int L, const float* s1, const float* t1, int swish,
+                           void* stream) {
+  if (!x || !w || !y || B <= 0 || L <= 0) return -22;
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  dim3 grid(sa_div_up(L, 256), B);
+  if (dtype == SA_BF16)
+    hipLaunchKernelGGL(sa_convCto1_kernel<bf16_t>, grid, dim3(256), 0, st,
+                       reinterpret_cast<const bf16_t*>(x), w, bias, y, L, s1, t1, swish);
+  else
+    hipLaunchKernelGGL(sa_convCto1_kernel<float>, grid, dim3(256), 0, st,
+                       reinterpret_cast<const float*>(x), w, bias, y, L, s1, t1, swish);
+  hipError_t e = hipGetLastError();
+  return e == hipSuccess ? 0 : -(int)e;
+}
+
+// slab[wg][c][k] = sum_{l in chunk} u[b][l + kk - 7] * P(v[b][l][c]),  kk = flip ? 14-k : k
+// encoder.0 wgrad: u = feats, v = d y0 (flip 0);  decoder.8 wgrad: u = d recon, v = y8 with the
+// InstanceNorm+swish prologue (flip 1).  Also slab[wg][480 + c] = sum_l P(v)[l][c] is NOT
+// produced here; bias gradients come from the per-(b,c) sums of the producing kernels.
+template <typename T>
+__global__ __launch_bounds__(256) void sa_wgrad1C_kernel(const float* __restrict__ u,
+                                                         const T* __restrict__ v,
+                                                         float* __restrict__ slabs, int L,
+                                                         int chunk, int flip,
+                                                         const float* __restrict__ s1,
+                                                         const float* __restrict__ t1, int swish) {
+  constexpr int VEC = Tr<T>::VEC, CH = SA_C32 / VEC, RPP = 256 / CH, TILE = 256, PITCH = 33;
+  __shared__ float us[TILE + SA_K15 - 1];
+  __shared__ float vs[TILE * PITCH];
+  const int tid = threadIdx.x, b = blockIdx.y;
+  const int lbeg = blockIdx.x * chunk;
+  int lend = lbeg + chunk; if (lend > L) lend = L;
+  const int c = tid % CH, r0 = tid / CH;
+  float sc[VEC], sh[VEC];
+#pragma unroll
+  for (int j = 0; j < VEC; ++j) {
+    sc[j] = s1 ? s1[(size_t)b * SA_C32 + c * VEC + j] : 1.0f;
+    sh[j] = t1 ? t1[(size_t)b * SA_C32 + c * VEC + j] : 0.0f;
+  }
+  const bool tr_on = (s1 != nullptr) || swish;
+  // thread -> (tap k, channel pair)
+  const int k = tid % SA_K15, cp = tid / SA_K15;           // cp < 16 for tid < 240
+  const int kk = flip ? SA_K15 - 1 - k : k;
+  float a0 = 0.0f, a1 = 0.0f;
+  for (int l0 = lbeg; l0 < lend; l0 += TILE) {
+    for (int i = tid; i < TILE + SA_K15 - 1; i += 256) {
+      const int g = l0 + i - 7;
+      us[i] = (g >= 0 && g < L) ? u[(size_t)b * L + g] : 0.0f;
+    }
+    for (int r = r0; r < TILE; r += RPP) {
+      const int g = l0 + r;
+      float f[VEC];
+#pragma unroll
+      for (int j = 0; j < VEC; ++j) f[j] = 0.0f;
+      if (g < lend) {
+        const uint4 q = *reinterpret_cast<const uint4*>(v + ((size_t)b * L + g) * SA_C32 + c * VEC);
+        Tr<T>::unpack(q, f);
+        if (tr_on) {
+#pragma unroll
+          for (int j = 0; j < VEC; ++j) {
+            float z = fmaf(f[j], sc[j], sh[j]);
+            f[j] = swish ? sa_swish(z) : z;
+          }
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < VEC; ++j) vs[r * PITCH + c * VEC + j] = f[j];
+    }
+    __syncthreads();
+    if (tid < SA_K15 * 16) {
+#pragma unroll 8
+      for (int p = 0; p < TILE; ++p) {
+        const float uv = us[p + kk];
+        a0 = fmaf(uv, vs[p * PITCH + 2 * cp], a0);
+        a1 = fmaf(uv, vs[p * PITCH + 2 * cp + 1], a1);
+      }
+    }
+    __syncthreads();
+  }
+  if (tid < SA_K15 * 16) {
+    float* slab = slabs + ((size_t)b * gridDim.x + blockIdx.x) * (SA_C32 * SA_K15);
+    slab[(2 * cp) * SA_K15 + k] = a0;
+    slab[(2 * cp + 1) * SA_K15 + k] = a1;
+  }
+}
+
+extern "C" int sa_wgrad1C_nchunk(int L, int chunk) { return sa_div_up(L, chunk); }
+
+extern "C" int sa_wgrad1C(int dtype, const float* u, const void* v, float* slabs, int B, int L,
+                          int chunk, int flip, const float* s1, const float* t1, int swish,
+                          void* stream) {
+  if (!u || !v || !slabs || B <= 0 || L <= 0 || chunk <= 0 || chunk % 256) return -22;
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  dim3 grid(sa_div_up(L, chunk), B);
+  if (dtype == SA_BF16)
+    hipLaunchKernelGGL(sa_wgrad1C_kernel<bf16_t>, grid, dim3(256), 0, st, u,
+                       reinterpret_cast<const bf16_t*>(v), slabs, L, chunk, flip, s1, t1, swish);
+  else
+    hipLaunchKernelGGL(sa_wgrad1C_kernel<float>, grid, dim3(256), 0, st, u,
+                       reinterpret_cast<const float*>(v), slabs, L, chunk, flip, s1, t1, swish);
+  hipError_t e = hipGetLastError();
+  return e == hipSuccess ? 0 : -(int)e;
+}
+
+// dst[i] (=|+=) sum_k slabs[k][i]   (fixed order, double accumulate)
+__global__ void sa_sum_slabs_kernel(const float* __restrict__ slabs, float* __restrict__ dst,
+                                    int nslab, int n, int accumulate) {
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+    double s = 0.0;
+    for (int k = 0; k < nslab; ++k) s += (double)slabs[(size_t)k * n + i];
+    dst[i] = accumulate ? dst[i] + (float)s : (float)s;
+  }
+}
+
+extern "C" int sa_sum_slabs(const float* slabs, float* dst, int nslab, int n, int accumulate,
+                            void* stream) {
+  if (!slabs || !dst || nslab <= 0 || n <= 0) return -22;
+  hipLaunchKernelGGL(sa_sum_slabs_kernel, dim3(sa_div_up(n, 256)), dim3(256), 0,
+                     reinterpret_cast<hipStream_t>(stream), slabs, dst, nslab, n, accumulate);
+  hipError_t e = hipGetLastError();
+  return e == hipSuccess ? 0 : -(int)e;
+}

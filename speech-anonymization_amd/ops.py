@@ -1,0 +1,324 @@
+"""Thin torch-tensor wrappers over the C ABI (one function per entry point family).
+
+Tensors are device memory handles only; all arithmetic happens in libsa_hip.so on the
+current torch stream.  Activations are channels-last [B, L, C] (see include/sa_hip.h).
+"""
+import ctypes as C
+
+import torch
+
+from . import _lib as L
+
+# ------------------------------------------------------------------------------------
+# conv geometry: tap tables of the row-gather GEMM for each kind of layer
+# ------------------------------------------------------------------------------------
+UP2 = [[(1, 0), (0, 2), (-1, 4)], [(1, 1), (0, 3)]]      # k5 s2 p2 (op1): convT fwd / conv-s2 dgrad
+
+
+def taps_conv(K, dil, pad):
+    """Conv1d forward (any stride via SA): input row = m*SA + k*dil - pad."""
+    return [[(k * dil - pad, k) for k in range(K)]]
+
+
+def taps_conv_dgrad_s1(K, dil, pad):
+    """stride-1 Conv1d dgrad: dx[i] = sum_k dy[i + pad - k*dil] W[k]^T."""
+    return [[(pad - k * dil, k) for k in range(K)]]
+
+
+def taps_convT_dgrad(K=5, pad=2):
+    """ConvTranspose1d(stride 2) dgrad = stride-2 conv over dy (SA = 2)."""
+    return [[(k - pad, k) for k in range(K)]]
+
+
+def _f(t):
+    return L.ptr(t)
+
+
+def pack_weights(w, kind, dtype):
+    """w: fp32 parameter in PyTorch layout.  kind: conv_fwd | conv_dgrad | convT_fwd |
+    convT_dgrad.  Returns the fragment-major operand image (flat tensor of `dtype`)."""
+    lib = L.load()
+    if kind in ("conv_fwd", "conv_dgrad"):
+        Cout, Cin, Kw = w.shape
+        if kind == "conv_fwd":
+            K, N, sk, sn = Cin, Cout, Kw, Cin * Kw
+        else:
+            K, N, sk, sn = Cout, Cin, Cin * Kw, Kw
+    else:
+        Cin, Cout, Kw = w.shape
+        if kind == "convT_fwd":
+            K, N, sk, sn = Cin, Cout, Cout * Kw, Kw
+        else:
+            K, N, sk, sn = Cout, Cin, Kw, Cout * Kw
+    out = torch.empty(Kw * K * N, dtype=dtype, device=w.device)
+    L.check(lib.sa_pack_weights(L.dt_code(dtype), _f(w), _f(out), Kw, K, N, sk, sn, 1, L.stream()),
+            "sa_pack_weights")
+    return out
+
+
+def conv_gemm(x, wp, bias, cin, cout, sa, u, phases, Lout, s1=None, t1=None, s2=None, t2=None,
+              swish=False, relu=False, want_stats=False, out=None):
+    """x [B, Lin, cin] -> y [B, Lout, cout] (+ per-tile partial stats [B, ntiles, cout, 2])."""
+    lib = L.load()
+    B, Lin, _ = x.shape
+    assert x.shape[2] == cin
+    y = out if out is not None else torch.empty(B, Lout, cout, dtype=x.dtype, device=x.device)
+    nt = lib.sa_conv_gemm_ntiles(Lout, u)
+    stats = torch.empty(B, nt, cout, 2, dtype=torch.float32, device=x.device) if want_stats else None
+    a = L.SaConvArgs()
+    a.x, a.wp, a.bias, a.y = _f(x), _f(wp), _f(bias), _f(y)
+    a.s1, a.t1, a.s2, a.t2 = _f(s1), _f(t1), _f(s2), _f(t2)
+    a.swish, a.relu, a.stats = int(swish), int(relu), _f(stats)
+    a.B, a.Lin, a.Lout = B, Lin, Lout
+    a.taps = L.make_taps(phases)
+    L.check(lib.sa_conv_gemm(L.dt_code(x.dtype), cin, cout, sa, u, C.byref(a), L.stream()),
+            f"sa_conv_gemm({cin},{cout},{sa},{u})")
+    return (y, stats) if want_stats else y
+
+
+def wgrad(x, dy, cin, cout, sa, u, taps, Mrows, dst, dst_strides, s1=None, t1=None, s2=None,
+          t2=None, swish=False, accumulate=False, target_wgs=768):
+    """taps: list of (row_offset, phase) per weight tap.  dst: fp32 parameter-gradient tensor in
+    PyTorch layout; dst_strides = (s_ci, s_co, s_tap)."""
+    lib = L.load()
+    B, Lin, _ = x.shape
+    Ldy = dy.shape[1]
+    nt = len(taps)
+    chunk = max(64, -(-Mrows * nt * B // target_wgs))
+    chunk = -(-chunk // 64) * 64
+    nchunk = -(-Mrows // chunk)
+    slabs = torch.empty(B * nchunk * nt * cin * cout, dtype=torch.float32, device=x.device)
+    a = L.SaWgradArgs()
+    a.x, a.dy, a.slabs = _f(x), _f(dy), _f(slabs)
+    a.s1, a.t1, a.s2, a.t2, a.swish = _f(s1), _f(t1), _f(s2), _f(t2), int(swish)
+    a.B, a.Lin, a.Ldy, a.Mrows, a.chunk, a.nchunk, a.ntaps = B, Lin, Ldy, Mrows, chunk, nchunk, nt
+    for i, (off, ph) in enumerate(taps):
+        a.off[i], a.ph[i] = off, ph
+    L.check(lib.sa_wgrad(L.dt_code(x.dtype), cin, cout, sa, u, C.byref(a), L.stream()),
+            f"sa_wgrad({cin},{cout},{sa},{u})")
+    sk, sn, st = dst_strides
+    L.check(lib.sa_wgrad_reduce(_f(slabs), _f(dst), B * nchunk, nt, cin, cout, sk, sn, st,
+                                int(accumulate), L.stream()), "sa_wgrad_reduce")
+    return dst
+
+
+def conv1toC(x, w, bias, dtype, flip=False, want_stats=False):
+    lib = L.load()
+    B, Ln = x.shape
+    y = torch.empty(B, Ln, 32, dtype=dtype, device=x.device)
+    nt = lib.sa_conv1toC_ntiles(Ln)
+    stats = torch.empty(B, nt, 32, 2, dtype=torch.float32, device=x.device) if want_stats else None
+    L.check(lib.sa_conv1toC(L.dt_code(dtype), _f(x), _f(w), _f(bias), _f(y), B, Ln, int(flip),
+                            _f(stats), L.stream()), "sa_conv1toC")
+    return (y, stats) if want_stats else y
+
+
+def convCto1(x, w, bias, s1=None, t1=None, swish=False):
+    lib = L.load()
+    B, Ln, _ = x.shape
+    y = torch.empty(B, Ln, dtype=torch.float32, device=x.device)
+    L.check(lib.sa_convCto1(L.dt_code(x.dtype), _f(x), _f(w), _f(bias), _f(y), B, Ln, _f(s1), _f(t1),
+                            int(swish), L.stream()), "sa_convCto1")
+    return y
+
+
+def wgrad1C(u, v, dst, flip=False, s1=None, t1=None, swish=False, accumulate=False, chunk=2048):
+    lib = L.load()
+    B, Ln = u.shape
+    nch = lib.sa_wgrad1C_nchunk(Ln, chunk)
+    slabs = torch.empty(B * nch, 32 * 15, dtype=torch.float32, device=u.device)
+    L.check(lib.sa_wgrad1C(L.dt_code(v.dtype), _f(u), _f(v), _f(slabs), B, Ln, chunk, int(flip),
+                           _f(s1), _f(t1), int(swish), L.stream()), "sa_wgrad1C")
+    L.check(lib.sa_sum_slabs(_f(slabs), _f(dst), B * nch, 32 * 15, int(accumulate), L.stream()),
+            "sa_sum_slabs")
+    return dst
+
+
+def sum_partials(part, nbatch):
+    """part [nbatch * nslab, n] (any leading shape) -> [nbatch, n] fixed-order sums."""
+    lib = L.load()
+    n = part.shape[-2] * part.shape[-1] if part.dim() >= 3 else part.shape[-1]
+    total = part.numel()
+    nslab = total // (nbatch * n)
+    out = torch.empty(nbatch, n, dtype=torch.float32, device=part.device)
+    L.check(lib.sa_sum_partials(_f(part), _f(out), nbatch, nslab, n, L.stream()), "sa_sum_partials")
+    return out
+
+
+def fin_in_fwd(sums, B, Cc, n, gamma, beta, eps=1e-5):
+    lib = L.load()
+    o = torch.empty(4, B, Cc, dtype=torch.float32, device=sums.device)
+    L.check(lib.sa_fin_in_fwd(_f(sums), B, Cc, n, _f(gamma), _f(beta), C.c_float(eps), _f(o[0]),
+                              _f(o[1]), _f(o[2]), _f(o[3]), L.stream()), "sa_fin_in_fwd")
+    return o[0], o[1], o[2], o[3]          # mean, rstd, scale, shift
+
+
+def fin_bn_fwd(sums, Cc, count, gamma, beta, run_mean=None, run_var=None, eps=1e-5, momentum=0.1):
+    lib = L.load()
+    o = torch.empty(4, Cc, dtype=torch.float32, device=sums.device)
+    L.check(lib.sa_fin_bn_fwd(_f(sums), Cc, C.c_double(count), _f(gamma), _f(beta), C.c_float(eps),
+                              C.c_float(momentum), _f(run_mean), _f(run_var), _f(o[0]), _f(o[1]),
+                              _f(o[2]), _f(o[3]), L.stream()), "sa_fin_bn_fwd")
+    return o[0], o[1], o[2], o[3]
+
+
+def fin_norm_bwd(sums, lsums, groups, Cc, n, gamma, mean, rstd, sign=1.0, dgamma=None, dbeta=None):
+    lib = L.load()
+    o = torch.empty(3, groups, dtype=torch.float32, device=sums.device)
+    L.check(lib.sa_fin_norm_bwd(_f(sums), _f(lsums), groups, Cc, C.c_double(n), _f(gamma), _f(mean),
+                                _f(rstd), C.c_float(sign), _f(o[0]), _f(o[1]), _f(o[2]), _f(dgamma),
+                                _f(dbeta), L.stream()), "sa_fin_norm_bwd")
+    return o[0], o[1], o[2]
+
+
+def fin_bias(sums, B, Cc, db):
+    L.check(L.load().sa_fin_bias(_f(sums), B, Cc, _f(db), L.stream()), "sa_fin_bias")
+    return db
+
+
+def ew(kind, g, x, Cc, out=None, g2=None, s1=None, t1=None, mean=None, rstd=None, c1=None, c2=None,
+       c3=None, actbwd=False, xp_is_act=False, relu_mask=False, per_c=False, want_stats=True):
+    """kind: "stats" | "apply".  Returns partial stats [B, ntiles, C, 2] (or None)."""
+    lib = L.load()
+    B, Ln, _ = x.shape
+    nt = lib.sa_ew_ntiles(Ln)
+    stats = torch.empty(B, nt, Cc, 2, dtype=torch.float32, device=x.device) if want_stats else None
+    a = L.SaEwArgs()
+    a.g, a.g2, a.x, a.out = _f(g), _f(g2), _f(x), _f(out)
+    a.s1, a.t1, a.mean, a.rstd = _f(s1), _f(t1), _f(mean), _f(rstd)
+    a.c1, a.c2, a.c3 = _f(c1), _f(c2), _f(c3)
+    a.actbwd, a.xp_is_act, a.relu_mask = int(actbwd), int(xp_is_act), int(relu_mask)
+    a.bstride = 0 if per_c else Cc
+    a.stats, a.B, a.L = _f(stats), B, Ln
+    fn = lib.sa_ew_stats if kind == "stats" else lib.sa_ew_apply
+    L.check(fn(L.dt_code(x.dtype), Cc, C.byref(a), L.stream()), f"sa_ew_{kind}")
+    return stats
+
+
+def act_stats(x, s1, t1, swish=True):
+    lib = L.load()
+    B, Ln, Cc = x.shape
+    nt = lib.sa_ew_ntiles(Ln)
+    stats = torch.empty(B, nt, Cc, 2, dtype=torch.float32, device=x.device)
+    L.check(lib.sa_act_stats(L.dt_code(x.dtype), Cc, _f(x), _f(s1), _f(t1), int(swish), _f(stats), B,
+                             Ln, L.stream()), "sa_act_stats")
+    return stats
+
+
+def pool_fwd(r, scale, shift, noise=None, eps=1e-5):
+    lib = L.load()
+    B, Ln, _ = r.shape
+    nt = lib.sa_pool_ntiles(Ln)
+    part = torch.empty(B, nt, 128, 2, dtype=torch.float32, device=r.device)
+    L.check(lib.sa_pool_fwd(L.dt_code(r.dtype), _f(r), _f(scale), _f(shift), _f(part), B, Ln,
+                            L.stream()), "sa_pool_fwd")
+    sums = sum_partials(part, B)
+    pooled = torch.empty(B, 256, dtype=torch.float32, device=r.device)
+    mean = torch.empty(B, 128, dtype=torch.float32, device=r.device)
+    sd = torch.empty(B, 128, dtype=torch.float32, device=r.device)
+    L.check(lib.sa_pool_fin(_f(sums), B, Ln, _f(noise), C.c_float(eps), _f(pooled), _f(mean), _f(sd),
+                            L.stream()), "sa_pool_fin")
+    return pooled, mean, sd
+
+
+def pool_bwd(r, scale, shift, dpooled, mean, sd):
+    lib = L.load()
+    B, Ln, _ = r.shape
+    g = torch.empty_like(r)
+    L.check(lib.sa_pool_bwd(L.dt_code(r.dtype), _f(r), _f(scale), _f(shift), _f(dpooled), _f(mean),
+                            _f(sd), _f(g), B, Ln, L.stream()), "sa_pool_bwd")
+    return g
+
+
+def dense(X, W, bias, N, K, ps=None, pt=None, relu=False, transpose_w=False):
+    """Y[M,N] = act(P(X)[M,K] @ Wm + bias).  W is an nn.Linear weight; transpose_w=False uses
+    Wm[k][n] = W[n][k] (forward), True uses Wm[k][n] = W[k][n] (data gradient)."""
+    lib = L.load()
+    M = X.shape[0]
+    Y = torch.empty(M, N, dtype=torch.float32, device=X.device)
+    sbk, sbn = (W.shape[1], 1) if transpose_w else (1, W.shape[1])
+    L.check(lib.sa_dense(_f(X), X.shape[1], _f(ps), _f(pt), _f(W), sbk, sbn, _f(bias), _f(Y), N, M, N,
+                         K, int(relu), L.stream()), "sa_dense")
+    return Y
+
+
+def colsums(X, H=None, hmean=None, hrstd=None):
+    lib = L.load()
+    M, N = X.shape
+    s = torch.empty(N, 2, dtype=torch.float32, device=X.device)
+    L.check(lib.sa_colsums(_f(X), _f(H), _f(hmean), _f(hrstd), M, N, _f(s), L.stream()), "sa_colsums")
+    return s
+
+
+def bn2d_bwd(G, H, sums, count, gamma, mean, rstd, relu_mask):
+    lib = L.load()
+    M, N = G.shape
+    dH = torch.empty_like(G)
+    L.check(lib.sa_bn2d_bwd(_f(G), _f(H), _f(sums), C.c_double(count), _f(gamma), _f(mean), _f(rstd),
+                            int(relu_mask), M, N, _f(dH), L.stream()), "sa_bn2d_bwd")
+    return dH
+
+
+def dense_wgrad(dY, X, dW, ps=None, pt=None):
+    lib = L.load()
+    M, N = dY.shape
+    K = X.shape[1]
+    L.check(lib.sa_dense_wgrad(_f(dY), _f(X), _f(ps), _f(pt), M, N, K, _f(dW), L.stream()),
+            "sa_dense_wgrad")
+    return dW
+
+
+def log_softmax(X):
+    Y = torch.empty_like(X)
+    L.check(L.load().sa_log_softmax(_f(X), _f(Y), X.shape[0], X.shape[1], L.stream()), "sa_log_softmax")
+    return Y
+
+
+def log_softmax_bwd(dY, Y):
+    dX = torch.empty_like(Y)
+    L.check(L.load().sa_log_softmax_bwd(_f(dY), _f(Y), _f(dX), Y.shape[0], Y.shape[1], L.stream()),
+            "sa_log_softmax_bwd")
+    return dX
+
+
+def recon_loss(a, b, kind, want_grad=True):
+    """kind "l1" | "mse"; returns (loss[1], grad like a or None)."""
+    lib = L.load()
+    n = a.numel()
+    loss = torch.empty(1, dtype=torch.float32, device=a.device)
+    grad = torch.empty_like(a) if want_grad else None
+    ws = torch.empty(lib.sa_loss_workspace_bytes() // 8, dtype=torch.float64, device=a.device)
+    L.check(lib.sa_recon_loss(_f(a), _f(b), C.c_longlong(n), 0 if kind == "l1" else 1, _f(grad),
+                              _f(loss), _f(ws), L.stream()), "sa_recon_loss")
+    return loss, grad
+
+
+def cls_losses(logp, label, want_grad=True):
+    lib = L.load()
+    B, NC = logp.shape
+    out = torch.empty(2, dtype=torch.float32, device=logp.device)
+    dn = torch.empty_like(logp) if want_grad else None
+    dc = torch.empty_like(logp) if want_grad else None
+    L.check(lib.sa_cls_losses(_f(logp), _f(label), B, NC, _f(out), _f(dn), _f(dc), L.stream()),
+            "sa_cls_losses")
+    return out, dn, dc
+
+
+def cosine_loss(x1, x2, want_grad=False):
+    lib = L.load()
+    B, S, D = x1.shape
+    rl = torch.empty(B * S, dtype=torch.float32, device=x1.device)
+    loss = torch.empty(1, dtype=torch.float32, device=x1.device)
+    dx1 = torch.empty_like(x1) if want_grad else None
+    L.check(lib.sa_cosine_loss(_f(x1), _f(x2), B, S, D, _f(rl), _f(loss), _f(dx1), L.stream()),
+            "sa_cosine_loss")
+    return loss, dx1
+
+
+def cluster_mi(X, y, idx=None, ncls=2, k=3):
+    lib = L.load()
+    iters, n = (idx.shape if idx is not None else (1, X.shape[0]))
+    mi = torch.empty(iters, dtype=torch.float32, device=X.device)
+    L.check(lib.sa_cluster_mi(_f(X), _f(y), _f(idx), iters, n, X.shape[1], ncls, k, _f(mi), L.stream()),
+            "sa_cluster_mi")
+    return mi

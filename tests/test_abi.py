@@ -1,0 +1,54 @@
+"""CPU checks of the drop-in boundary: libsa_hip.so builds, loads, and exports exactly the
+entry points include/sa_hip.h declares (no compute without a GPU)."""
+import ctypes
+import os
+import re
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared():
+    src = open(os.path.join(ROOT, "include", "sa_hip.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"^\s*int\s+(sa_\w+)\s*\(", src, flags=re.M)))
+
+
+def test_library_exports_every_declared_symbol():
+    import __graft_entry__ as g
+    g.build()
+    from speech_anonymization_amd import _lib
+    lib = ctypes.CDLL(_lib.LIB_PATH)
+    decl = _declared()
+    assert len(decl) >= 38
+    for name in decl:
+        assert hasattr(lib, name), f"{name} declared in include/sa_hip.h but not exported"
+    assert sorted(_lib.SYMBOLS) == decl, "ctypes binding and header disagree"
+
+
+def test_ctypes_structs_match_header_field_order():
+    from speech_anonymization_amd import _lib
+    src = open(os.path.join(ROOT, "include", "sa_hip.h")).read()
+    for st in (_lib.SaConvArgs, _lib.SaWgradArgs, _lib.SaEwArgs, _lib.SaTaps):
+        body = re.search(r"typedef struct %s \{(.*?)\} %s;" % (st.__name__, st.__name__), src, re.S).group(1)
+        body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
+        names = []
+        for decl in body.split(";"):
+            decl = decl.strip()
+            if not decl:
+                continue
+            for part in decl.split(","):
+                m = re.search(r"(\w+)\s*(\[[^\]]*\])*\s*$", part.strip())
+                names.append(m.group(1))
+        assert names == [f[0] for f in st._fields_], st.__name__
+
+
+def test_missing_library_fails_loudly(monkeypatch):
+    from speech_anonymization_amd import _lib
+    monkeypatch.setattr(_lib, "_lib", None)
+    monkeypatch.setattr(_lib, "LIB_PATH", "/nonexistent/libsa_hip.so")
+    try:
+        _lib.load()
+    except _lib.SaHipError as e:
+        assert "no CPU fallback" in str(e)
+    else:
+        raise AssertionError("load() must raise when the HIP library is missing")

@@ -1,0 +1,405 @@
+"""Per-kernel parity: every C-ABI entry point against the CPU oracle ops (plain PyTorch CPU
+fp32 / the oracle package) on seeded inputs.  fp32 path: near bit-level; bf16 path: the
+north_star tolerance (rel-MSE <= 1e-4), measured against a reference fed the same
+bf16-rounded inputs."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+DT = [torch.float32, torch.bfloat16]
+
+
+def dev():
+    return torch.device("cuda:0")
+
+
+def rel_mse(a, b):
+    a, b = a.double().cpu(), b.double().cpu()
+    return float(((a - b) ** 2).sum() / (b ** 2).sum().clamp_min(1e-30))
+
+
+def tol(dt):
+    return 1e-10 if dt == torch.float32 else 2e-5
+
+
+def rnd(dt, *shape, seed=0, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    x = torch.randn(*shape, generator=g) * scale
+    return x.to(dt).float()          # values exactly representable in dt
+
+
+def cl(x_bcl, dt):
+    """[B,C,L] cpu fp32 -> channels-last [B,L,C] device tensor of dtype dt."""
+    return x_bcl.permute(0, 2, 1).contiguous().to(dev(), dt)
+
+
+def uncl(y_blc):
+    return y_blc.float().cpu().permute(0, 2, 1).contiguous()
+
+
+# (name, cin, cout, K, stride, dil, pad, transposed)
+LAYERS = [
+    ("enc2", 32, 64, 5, 2, 1, 2, False), ("enc5", 64, 64, 5, 1, 1, 2, False),
+    ("enc8", 64, 128, 5, 2, 1, 2, False), ("enc11", 128, 128, 5, 1, 1, 2, False),
+    ("tdnn0", 128, 128, 5, 1, 1, 0, False), ("tdnn3", 128, 128, 3, 1, 2, 0, False),
+    ("tdnn6", 128, 128, 3, 1, 3, 0, False),
+    ("dec1", 128, 64, 5, 2, 1, 2, True), ("dec5", 64, 32, 5, 2, 1, 2, True),
+]
+
+
+def ref_fwd(x, w, b, stride, dil, pad, transposed):
+    if transposed:
+        return F.conv_transpose1d(x, w, b, stride=stride, padding=pad, output_padding=1)
+    return F.conv1d(x, w, b, stride=stride, padding=pad, dilation=dil)
+
+
+@pytest.mark.parametrize("dt", DT)
+@pytest.mark.parametrize("layer", LAYERS, ids=[l[0] for l in LAYERS])
+def test_conv_fwd_dgrad_wgrad(layer, dt):
+    from speech_anonymization_amd import ops
+    name, cin, cout, K, stride, dil, pad, tr = layer
+    B, Lin = 2, 300 if stride == 1 or tr else 300
+    x = rnd(dt, B, cin, Lin, seed=1)
+    wshape = (cin, cout, K) if tr else (cout, cin, K)
+    w = rnd(dt, *wshape, seed=2, scale=(cin * K) ** -0.5)
+    bias = rnd(torch.float32, cout, seed=3, scale=0.1)
+    x.requires_grad_(True)
+    w.requires_grad_(True)
+    y = ref_fwd(x, w, bias, stride, dil, pad, tr)
+    Lout = y.shape[2]
+    gy = rnd(dt, B, cout, Lout, seed=4)
+    gx, gw = torch.autograd.grad(y, (x, w), gy)
+
+    xd, wd, bd = cl(x.detach(), dt), w.detach().to(dev()), bias.to(dev())
+    # ---- forward ----
+    if tr:
+        wp = ops.pack_weights(wd, "convT_fwd", dt)
+        yd, st = ops.conv_gemm(xd, wp, bd, cin, cout, 1, 2, ops.UP2, Lout, want_stats=True)
+    else:
+        wp = ops.pack_weights(wd, "conv_fwd", dt)
+        yd, st = ops.conv_gemm(xd, wp, bd, cin, cout, stride, 1, ops.taps_conv(K, dil, pad), Lout,
+                               want_stats=True)
+    torch.cuda.synchronize()
+    assert rel_mse(uncl(yd), y.detach()) < tol(dt), name
+    # epilogue statistics = sum / sumsq of the stored values per (b, c)
+    s = st.sum(dim=1).cpu()
+    yy = yd.float().cpu()
+    assert torch.allclose(s[..., 0], yy.sum(dim=1), rtol=1e-4, atol=1e-3)
+    assert torch.allclose(s[..., 1], (yy * yy).sum(dim=1), rtol=1e-4, atol=1e-3)
+    # ---- dgrad ----
+    gyd = cl(gy, dt)
+    if tr:
+        wpd = ops.pack_weights(wd, "convT_dgrad", dt)
+        gxd = ops.conv_gemm(gyd, wpd, None, cout, cin, 2, 1, ops.taps_convT_dgrad(), Lin)
+    elif stride == 2:
+        wpd = ops.pack_weights(wd, "conv_dgrad", dt)
+        gxd = ops.conv_gemm(gyd, wpd, None, cout, cin, 1, 2, ops.UP2, Lin)
+    else:
+        wpd = ops.pack_weights(wd, "conv_dgrad", dt)
+        gxd = ops.conv_gemm(gyd, wpd, None, cout, cin, 1, 1, ops.taps_conv_dgrad_s1(K, dil, pad), Lin)
+    torch.cuda.synchronize()
+    assert rel_mse(uncl(gxd), gx) < tol(dt), name + " dgrad"
+    # ---- wgrad ----
+    gwd = torch.zeros(wshape, device=dev())
+    if tr:
+        taps = [(1, 0), (1, 1), (0, 0), (0, 1), (-1, 0)]
+        ops.wgrad(xd, gyd, cin, cout, 1, 2, taps, Lin, gwd, (cout * K, K, 1))
+    else:
+        taps = [(k * dil - pad, 0) for k in range(K)]
+        ops.wgrad(xd, gyd, cin, cout, stride, 1, taps, Lout, gwd, (K, cin * K, 1))
+    torch.cuda.synchronize()
+    assert rel_mse(gwd, gw) < tol(dt), name + " wgrad"
+
+
+@pytest.mark.parametrize("dt", DT)
+def test_conv_prologue_relu(dt):
+    """IN affine + swish + BN affine in the prologue, zero padding applied AFTER the transform,
+    ReLU epilogue; ragged length (not a multiple of the 128-row tile)."""
+    from speech_anonymization_amd import ops
+    B, Cc, Lin, K = 3, 128, 517, 5
+    x = rnd(dt, B, Cc, Lin, seed=5)
+    w = rnd(dt, Cc, Cc, K, seed=6, scale=(Cc * K) ** -0.5)
+    s1, t1 = 1 + 0.2 * rnd(torch.float32, B, Cc, seed=7), 0.3 * rnd(torch.float32, B, Cc, seed=8)
+    s2, t2 = 1 + 0.2 * rnd(torch.float32, Cc, seed=9), 0.3 * rnd(torch.float32, Cc, seed=10)
+    z = x * s1[:, :, None] + t1[:, :, None]
+    a = (z * torch.sigmoid(z)) * s2[None, :, None] + t2[None, :, None]
+    a = a.to(dt).float()                                   # the kernel stages the operand in dt
+    y = F.relu(F.conv1d(a, w, None, padding=2))
+    wp = ops.pack_weights(w.to(dev()), "conv_fwd", dt)
+    yd = ops.conv_gemm(cl(x, dt), wp, None, Cc, Cc, 1, 1, ops.taps_conv(K, 1, 2), Lin,
+                       s1=s1.to(dev()), t1=t1.to(dev()), s2=s2.to(dev()), t2=t2.to(dev()),
+                       swish=True, relu=True)
+    torch.cuda.synchronize()
+    assert rel_mse(uncl(yd), y) < (1e-9 if dt == torch.float32 else 1e-4)
+
+
+@pytest.mark.parametrize("dt", DT)
+def test_small_channel_kernels(dt):
+    from speech_anonymization_amd import ops
+    B, Ln = 2, 1300
+    x = rnd(torch.float32, B, Ln, seed=11)
+    w0 = rnd(torch.float32, 32, 1, 15, seed=12, scale=0.25)
+    b0 = rnd(torch.float32, 32, seed=13, scale=0.1)
+    # encoder.0 forward
+    y0 = F.conv1d(x[:, None], w0, b0, padding=7)
+    y0d, st = ops.conv1toC(x.to(dev()), w0.to(dev()), b0.to(dev()), dt, want_stats=True)
+    torch.cuda.synchronize()
+    assert rel_mse(uncl(y0d), y0) < tol(dt)
+    assert torch.allclose(st.sum(1)[..., 0].cpu(), y0d.float().cpu().sum(1), rtol=1e-4, atol=1e-3)
+    # encoder.0 wgrad: dW[c][k] = sum x[l+k-7] * dy[l][c]
+    gy = rnd(dt, B, 32, Ln, seed=14)
+    w0r = w0.clone().requires_grad_(True)
+    (gw,) = torch.autograd.grad(F.conv1d(x[:, None], w0r, None, padding=7), w0r, gy)
+    gwd = torch.zeros(32, 1, 15, device=dev())
+    ops.wgrad1C(x.to(dev()), cl(gy, dt), gwd)
+    torch.cuda.synchronize()
+    assert rel_mse(gwd, gw) < tol(dt)
+    # decoder.8 forward with IN+swish prologue
+    v = rnd(dt, B, 32, Ln, seed=15)
+    s1, t1 = 1 + 0.2 * rnd(torch.float32, B, 32, seed=16), 0.3 * rnd(torch.float32, B, 32, seed=17)
+    w8 = rnd(torch.float32, 1, 32, 15, seed=18, scale=0.05)
+    b8 = rnd(torch.float32, 1, seed=19, scale=0.1)
+    z = v * s1[:, :, None] + t1[:, :, None]
+    a = (z * torch.sigmoid(z)).requires_grad_(True)
+    w8r = w8.clone().requires_grad_(True)
+    y8 = F.conv1d(a, w8r, b8, padding=7)
+    y8d = ops.convCto1(cl(v, dt), w8.to(dev()), b8.to(dev()), s1.to(dev()), t1.to(dev()), True)
+    torch.cuda.synchronize()
+    assert rel_mse(y8d.cpu(), y8.detach()[:, 0]) < 1e-9
+    # decoder.8 dgrad (conv1toC, flipped taps) and wgrad (wgrad1C, flipped, with prologue)
+    g8 = rnd(torch.float32, B, 1, Ln, seed=20)
+    ga, gw8 = torch.autograd.grad(y8, (a, w8r), g8)
+    gad = ops.conv1toC(g8[:, 0].contiguous().to(dev()), w8.to(dev()), None, dt, flip=True)
+    gw8d = torch.zeros(1, 32, 15, device=dev())
+    ops.wgrad1C(g8[:, 0].contiguous().to(dev()), cl(v, dt), gw8d, flip=True, s1=s1.to(dev()),
+                t1=t1.to(dev()), swish=True)
+    torch.cuda.synchronize()
+    assert rel_mse(uncl(gad), ga) < tol(dt)
+    assert rel_mse(gw8d, gw8) < 1e-9
+
+
+@pytest.mark.parametrize("dt", DT)
+@pytest.mark.parametrize("Cc", [32, 64, 128])
+def test_instance_norm_swish_backward(dt, Cc):
+    """two-phase IN + x*sigmoid(x) backward (sa_ew_stats -> sa_fin_norm_bwd -> sa_ew_apply)
+    against autograd through nn.InstanceNorm1d(affine) + the reference's GLU."""
+    from speech_anonymization_amd import ops
+    B, Ln = 2, 700
+    y = rnd(dt, B, Cc, Ln, seed=21).requires_grad_(True)
+    gamma = (1 + 0.1 * rnd(torch.float32, Cc, seed=22)).requires_grad_(True)
+    beta = (0.1 * rnd(torch.float32, Cc, seed=23)).requires_grad_(True)
+    z = F.instance_norm(y, weight=gamma, bias=beta, eps=1e-5)
+    a = z * torch.sigmoid(z)
+    ga = rnd(dt, B, Cc, Ln, seed=24)
+    gy, gg, gb = torch.autograd.grad(a, (y, gamma, beta), ga)
+
+    yd = cl(y.detach(), dt)
+    # forward statistics through the same finaliser the conv epilogue feeds
+    yy = yd.float()
+    part = torch.stack([yy.sum(1), (yy * yy).sum(1)], dim=-1).reshape(B, 1, Cc, 2).contiguous()
+    sums = ops.sum_partials(part, B)
+    mean, rstd, scale, shift = ops.fin_in_fwd(sums, B, Cc, Ln, gamma.detach().to(dev()),
+                                              beta.detach().to(dev()))
+    gad = cl(ga, dt)
+    dz = torch.empty_like(gad)
+    st = ops.ew("stats", gad, yd, Cc, out=dz, s1=scale, t1=shift, mean=mean, rstd=rstd, actbwd=True)
+    dgam, dbet = torch.zeros(Cc, device=dev()), torch.zeros(Cc, device=dev())
+    bs = ops.sum_partials(st, B)
+    c1, c2, c3 = ops.fin_norm_bwd(bs, bs, B * Cc, Cc, Ln, gamma.detach().to(dev()), mean, rstd,
+                                  dgamma=dgam, dbeta=dbet)
+    dy = torch.empty_like(gad)
+    st2 = ops.ew("apply", dz, yd, Cc, out=dy, c1=c1, c2=c2, c3=c3)
+    torch.cuda.synchronize()
+    t = 1e-9 if dt == torch.float32 else 1e-4
+    assert rel_mse(uncl(dy), gy) < t
+    assert rel_mse(dgam, gg) < t and rel_mse(dbet, gb) < t
+    db = torch.zeros(Cc, device=dev())
+    ops.fin_bias(ops.sum_partials(st2, B), B, Cc, db)
+    torch.cuda.synchronize()
+    assert torch.allclose(db.cpu(), dy.float().cpu().sum((0, 1)), atol=1e-2)
+
+
+@pytest.mark.parametrize("dt", DT)
+def test_relu_batchnorm_backward(dt):
+    """TDNN block: stored r = relu(conv); BatchNorm1d (train) statistics over (B, L)."""
+    from speech_anonymization_amd import ops
+    B, Cc, Ln = 3, 128, 411
+    y = rnd(dt, B, Cc, Ln, seed=31).requires_grad_(True)
+    gamma = (1 + 0.1 * rnd(torch.float32, Cc, seed=32)).requires_grad_(True)
+    beta = (0.1 * rnd(torch.float32, Cc, seed=33)).requires_grad_(True)
+    r = F.relu(y)
+    rm, rv = torch.zeros(Cc), torch.ones(Cc)
+    o = F.batch_norm(r, rm, rv, gamma, beta, training=True, momentum=0.1, eps=1e-5)
+    go = rnd(dt, B, Cc, Ln, seed=34)
+    gy, gg, gb = torch.autograd.grad(o, (y, gamma, beta), go)
+
+    rd = cl(r.detach(), dt)
+    rr = rd.float()
+    part = torch.stack([rr.sum(1), (rr * rr).sum(1)], dim=-1).reshape(B, 1, Cc, 2).contiguous()
+    sums = ops.sum_partials(part, 1)
+    rmd, rvd = torch.zeros(Cc, device=dev()), torch.ones(Cc, device=dev())
+    mean, rstd, scale, shift = ops.fin_bn_fwd(sums, Cc, B * Ln, gamma.detach().to(dev()),
+                                              beta.detach().to(dev()), rmd, rvd)
+    torch.cuda.synchronize()
+    assert torch.allclose(rmd.cpu(), rm, atol=1e-5) and torch.allclose(rvd.cpu(), rv, atol=1e-5)
+    ref_o = o.detach()
+    assert rel_mse((rr * scale + shift).cpu().permute(0, 2, 1), ref_o) < 1e-9
+    god = cl(go, dt)
+    st = ops.ew("stats", god, rd, Cc, mean=mean, rstd=rstd, per_c=True)
+    bs = ops.sum_partials(st, 1)
+    dgam, dbet = torch.zeros(Cc, device=dev()), torch.zeros(Cc, device=dev())
+    c1, c2, c3 = ops.fin_norm_bwd(bs, bs, Cc, Cc, B * Ln, gamma.detach().to(dev()), mean, rstd,
+                                  dgamma=dgam, dbeta=dbet)
+    dy = torch.empty_like(god)
+    ops.ew("apply", god, rd, Cc, out=dy, c1=c1, c2=c2, c3=c3, relu_mask=True, per_c=True,
+           want_stats=False)
+    torch.cuda.synchronize()
+    t = 1e-9 if dt == torch.float32 else 1e-4
+    assert rel_mse(uncl(dy), gy) < t
+    assert rel_mse(dgam, gg) < t and rel_mse(dbet, gb) < t
+
+
+@pytest.mark.parametrize("dt", DT)
+@pytest.mark.parametrize("Ln", [20146, 333])
+def test_statistics_pooling_reshape_quirk(dt, Ln):
+    """reshape (not transpose) of [B,128,L] to [B,L,128] before StatisticsPooling
+    (models/ConvAutoEncoder.py:61-66) -- forward and backward."""
+    from oracle.convae import StatisticsPooling
+    from speech_anonymization_amd import ops
+    B, Cc = 2, 128
+    r = rnd(dt, B, Cc, Ln, seed=41).abs()
+    sc, sh = 1 + 0.1 * rnd(torch.float32, Cc, seed=42), 0.1 * rnd(torch.float32, Cc, seed=43)
+    xbn = (r * sc[None, :, None] + sh[None, :, None]).requires_grad_(True)
+    pooled = StatisticsPooling()(xbn.reshape(B, Ln, Cc)).squeeze(1)
+    gp = rnd(torch.float32, B, 256, seed=44)
+    (gx,) = torch.autograd.grad(pooled, xbn, gp)
+    rd = cl(r, dt)
+    pd, mean, sd = ops.pool_fwd(rd, sc.to(dev()), sh.to(dev()))
+    g = ops.pool_bwd(rd, sc.to(dev()), sh.to(dev()), gp.to(dev()), mean, sd)
+    torch.cuda.synchronize()
+    assert rel_mse(pd, pooled.detach()) < 1e-9
+    assert rel_mse(uncl(g), gx) < (1e-9 if dt == torch.float32 else 2e-5)
+    # noise term of speechbrain's pooling: mean += eps*((1-9)*g+9)
+    noise = torch.rand(B, 128)
+    pn, _, _ = ops.pool_fwd(rd, sc.to(dev()), sh.to(dev()), noise=noise.to(dev()))
+    ref = StatisticsPooling(noise=noise)(xbn.detach().reshape(B, Ln, Cc)).squeeze(1)
+    torch.cuda.synchronize()
+    assert rel_mse(pn, ref) < 1e-9
+
+
+def test_fc_head_and_losses():
+    from speech_anonymization_amd import ops
+    B = 10
+    torch.manual_seed(0)
+    lin1, bn1 = torch.nn.Linear(256, 128), torch.nn.BatchNorm1d(128)
+    lin2, bn2 = torch.nn.Linear(128, 64), torch.nn.BatchNorm1d(64)
+    lin3 = torch.nn.Linear(64, 2)
+    p = torch.randn(B, 256, requires_grad=True)
+    h1 = F.relu(lin1(p)); n1 = bn1(h1)
+    h2 = F.relu(lin2(n1)); n2 = bn2(h2)
+    logits = lin3(n2)
+    logp = F.log_softmax(logits, 1)
+    gender = torch.arange(B) % 2
+    nll = F.nll_loss(logp, gender)
+    conf = F.mse_loss(logp, torch.ones_like(logp) * -0.6931)
+    loss = 0.9 * nll + 0.3 * conf
+    params = [lin1.weight, lin1.bias, bn1.weight, bn1.bias, lin2.weight, lin2.bias, bn2.weight,
+              bn2.bias, lin3.weight, lin3.bias, p]
+    grads = torch.autograd.grad(loss, params)
+
+    d = dev()
+    g = lambda t: t.detach().to(d).contiguous()
+    H1 = ops.dense(g(p), g(lin1.weight), g(lin1.bias), 128, 256, relu=True)
+    m1, r1, s1, t1 = ops.fin_bn_fwd(ops.colsums(H1), 128, B, g(bn1.weight), g(bn1.bias))
+    H2 = ops.dense(H1, g(lin2.weight), g(lin2.bias), 64, 128, ps=s1, pt=t1, relu=True)
+    m2, r2, s2, t2 = ops.fin_bn_fwd(ops.colsums(H2), 64, B, g(bn2.weight), g(bn2.bias))
+    LG = ops.dense(H2, g(lin3.weight), g(lin3.bias), 2, 64, ps=s2, pt=t2)
+    LP = ops.log_softmax(LG)
+    out, dn, dc = ops.cls_losses(LP, gender.to(d))
+    torch.cuda.synchronize()
+    assert rel_mse(LP, logp.detach()) < 1e-9
+    assert abs(float(out[0]) - float(nll)) < 1e-5 and abs(float(out[1]) - float(conf)) < 1e-5
+    dLP = 0.9 * dn + 0.3 * dc
+    dLG = ops.log_softmax_bwd(dLP, LP)
+    dW3 = ops.dense_wgrad(dLG, H2, torch.empty(2, 64, device=d), ps=s2, pt=t2)
+    dN2 = ops.dense(dLG, g(lin3.weight), None, 64, 2, transpose_w=True)
+    S2 = ops.colsums(dN2, H2, m2, r2)
+    dH2 = ops.bn2d_bwd(dN2, H2, S2, B, g(bn2.weight), m2, r2, True)
+    dW2 = ops.dense_wgrad(dH2, H1, torch.empty(64, 128, device=d), ps=s1, pt=t1)
+    dN1 = ops.dense(dH2, g(lin2.weight), None, 128, 64, transpose_w=True)
+    S1 = ops.colsums(dN1, H1, m1, r1)
+    dH1 = ops.bn2d_bwd(dN1, H1, S1, B, g(bn1.weight), m1, r1, True)
+    dW1 = ops.dense_wgrad(dH1, g(p), torch.empty(128, 256, device=d))
+    dP = ops.dense(dH1, g(lin1.weight), None, 256, 128, transpose_w=True)
+    torch.cuda.synchronize()
+    got = [dW1, dH1.sum(0), S1[:, 1], S1[:, 0], dW2, dH2.sum(0), S2[:, 1], S2[:, 0], dW3,
+           dLG.sum(0), dP]
+    for a, b in zip(got, grads):
+        assert rel_mse(a, b) < 1e-8
+
+
+@pytest.mark.parametrize("kind", ["l1", "mse"])
+def test_recon_loss(kind):
+    from oracle import losses
+    from speech_anonymization_amd import ops
+    a = rnd(torch.float32, 3, 72, 80, seed=51).requires_grad_(True)
+    b = rnd(torch.float32, 3, 72, 80, seed=52)
+    ref = losses.recon_loss(a, b, kind)
+    (ga,) = torch.autograd.grad(ref, a)
+    loss, grad = ops.recon_loss(a.detach().to(dev()), b.to(dev()), kind)
+    torch.cuda.synchronize()
+    assert abs(float(loss) - float(ref)) < 1e-6 * max(1.0, abs(float(ref)))
+    assert rel_mse(grad, ga) < 1e-10
+
+
+def test_cosine_and_mi_golden(golden_dir):
+    """the reference's own CosineSimilarityLoss / ClusterMI / GroupSamplingMI outputs
+    (tests/golden/losses.npz, generated from /root/reference by oracle/gen_golden.py)."""
+    import os
+    from speech_anonymization_amd import ops
+    z = np.load(os.path.join(golden_dir, "losses.npz"))
+    x1, x2 = torch.from_numpy(z["x1"]), torch.from_numpy(z["x2"])
+    loss, dx1 = ops.cosine_loss(x1.to(dev()), x2.to(dev()), want_grad=True)
+    torch.cuda.synchronize()
+    assert abs(float(loss) - float(z["cos_loss"])) < 1e-5
+    x1r = x1.clone().requires_grad_(True)
+    from oracle.losses import cosine_similarity_loss
+    (g,) = torch.autograd.grad(cosine_similarity_loss(x1r, x2), x1r)
+    assert rel_mse(dx1, g) < 1e-8
+    X, y = torch.from_numpy(z["X"]).to(dev()), torch.from_numpy(z["y"]).to(dev())
+    mi = ops.cluster_mi(X, y)
+    idx = torch.from_numpy(z["idx_sets"]).long().to(dev())
+    mis = ops.cluster_mi(X, y, idx)
+    torch.cuda.synchronize()
+    assert abs(float(mi[0]) - float(z["mi"])) < 1e-4
+    assert np.allclose(mis.cpu().numpy(), z["mi_list"], atol=1e-4)
+
+
+@pytest.mark.parametrize("mode", ["utterance", "batch"])
+def test_fbank_and_normalization(mode):
+    from oracle import features as OF
+    from speech_anonymization_amd import Fbank, InputNormalization
+    B, N = 3, 11360
+    wav = OF.synthetic_wave(B, N, seed=8886)
+    wav[2, 7000:] = 0.0                                          # zero-padded tail
+    lens = torch.tensor([1.0, 0.83, 0.61])
+    ofb, onorm = OF.Fbank(top_db_mode=mode), OF.InputNormalization(update_until_epoch=4)
+    fb, norm = Fbank(top_db_mode=mode).to(dev()), InputNormalization(update_until_epoch=4).to(dev())
+    f_ref = ofb(wav)
+    f = fb(wav.to(dev()))
+    torch.cuda.synchronize()
+    assert f.raw.shape == (B, 72, 80)
+    assert rel_mse(f.clamped(), f_ref) < 1e-8
+    for epoch in (1, 1, 5):                                       # first call, running update, frozen
+        r_ref = OF.pad_to_multiple(onorm(f_ref, lens, epoch=epoch), 36)
+        r = norm(f, lens, epoch=epoch, pad_multiple=36)
+        torch.cuda.synchronize()
+        assert r.shape == r_ref.shape
+        assert rel_mse(r, r_ref) < 1e-8
+    sd = norm.state_dict()
+    assert sd["count"] == onorm.count
+    assert torch.allclose(sd["glob_mean"].cpu(), onorm.glob_mean, atol=1e-3)
+    assert torch.allclose(sd["glob_std"].cpu(), onorm.glob_std, atol=1e-3)
