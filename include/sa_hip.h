@@ -92,7 +92,7 @@ int sa_conv1toC(int dtype, const float* x, const float* w, const float* bias, vo
                 int flip, float* stats, void* stream);          /* stats [B][ntiles][32][2] */
 int sa_conv1toC_ntiles(int L);
 int sa_convCto1(int dtype, const void* x, const float* w, const float* bias, float* y, int B, int L,
-                const float* s1, const float* t1, int swish, void* stream);
+                const float* s1, const float* t1, int swish, int flip, void* stream);
 int sa_wgrad1C(int dtype, const float* u, const void* v, float* slabs, int B, int L, int chunk,
                int flip, const float* s1, const float* t1, int swish, void* stream);
 int sa_wgrad1C_nchunk(int L, int chunk);
@@ -116,16 +116,19 @@ int sa_ew_apply(int dtype, int C, const SaEwArgs* a, void* stream);
 int sa_ew_ntiles(int L);
 int sa_act_stats(int dtype, int C, const void* x, const float* s1, const float* t1, int swish,
                  float* stats, int B, int L, void* stream);
-int sa_sum_partials(const float* slabs, float* dst, int nbatch, int nslab, int n, void* stream);
-int sa_fin_in_fwd(const float* sums, int B, int C, int n, const float* gamma, const float* beta,
+int sa_sum_partials(const float* slabs, double* dst, int nbatch, int nslab, int n, void* stream);
+int sa_fin_in_fwd(const double* sums, int B, int C, int n, const float* gamma, const float* beta,
                   float eps, float* mean, float* rstd, float* scale, float* shift, void* stream);
-int sa_fin_bn_fwd(const float* sums, int C, double count, const float* gamma, const float* beta,
+int sa_fin_bn_fwd(const double* sums, int C, double count, const float* gamma, const float* beta,
                   float eps, float momentum, float* run_mean, float* run_var, float* mean,
                   float* rstd, float* scale, float* shift, void* stream);
-int sa_fin_norm_bwd(const float* sums, const float* lsums, int groups, int C, double n,
+int sa_fin_bn_eval(int C, const float* gamma, const float* beta, float eps, const float* run_mean,
+                   const float* run_var, float* mean, float* rstd, float* scale, float* shift,
+                   void* stream);
+int sa_fin_norm_bwd(const double* sums, const double* lsums, int groups, int C, double n,
                     const float* gamma, const float* mean, const float* rstd, float sign, float* c1,
                     float* c2, float* c3, float* dgamma, float* dbeta, void* stream);
-int sa_fin_bias(const float* sums, int B, int C, float* db, void* stream);
+int sa_fin_bias(const double* sums, int B, int C, float* db, void* stream);
 
 /* ---- classifier head + losses (sa_head.hip): TDNNSexClassifier.forward reshape + pooling
  * (models/ConvAutoEncoder.py:61-66), classify (:47-55), log_softmax (:68); losses at
@@ -133,7 +136,7 @@ int sa_fin_bias(const float* sums, int B, int C, float* db, void* stream);
 int sa_pool_fwd(int dtype, const void* r, const float* scale, const float* shift, float* part, int B,
                 int L, void* stream);                            /* part [B][ntiles][128][2] */
 int sa_pool_ntiles(int L);
-int sa_pool_fin(const float* sums, int B, int n, const float* noise, float eps, float* pooled,
+int sa_pool_fin(const double* sums, int B, int n, const float* noise, float eps, float* pooled,
                 float* mean, float* stdraw, void* stream);
 int sa_pool_bwd(int dtype, const void* r, const float* scale, const float* shift,
                 const float* dpooled, const float* mean, const float* stdraw, void* g, int B, int L,
@@ -142,8 +145,8 @@ int sa_dense(const float* X, int lda, const float* ps, const float* pt, const fl
              int sbn, const float* bias, float* Y, int ldy, int M, int N, int K, int relu,
              void* stream);
 int sa_colsums(const float* X, const float* H, const float* hmean, const float* hrstd, int M, int N,
-               float* sums, void* stream);
-int sa_bn2d_bwd(const float* G, const float* H, const float* sums, double count, const float* gamma,
+               double* sums, void* stream);
+int sa_bn2d_bwd(const float* G, const float* H, const double* sums, double count, const float* gamma,
                 const float* mean, const float* rstd, int relu_mask, int M, int N, float* dH,
                 void* stream);
 int sa_dense_wgrad(const float* dY, const float* X, const float* ps, const float* pt, int M, int N,

@@ -152,3 +152,25 @@ def synthetic_wave(B, N, seed=8886, rank=0):
     for f, a in ((220.0, 0.2), (1000.0, 0.1), (3400.0, 0.05)):
         w = w + a * np.sin(2 * np.pi * f * t)[None, :]
     return torch.from_numpy(np.clip(w, -1.0, 1.0).astype("float32"))
+
+
+def synthetic_feats(B, T, seed=1):
+    """Normalised-Fbank-like test features [B, T, 80] whose utterances differ in STRUCTURE
+    (harmonic ridges at utterance-specific Mel positions, different temporal modulation), not
+    just in scale: InstanceNorm removes per-utterance scale/offset, and with white-noise inputs
+    the classifier's pooled statistics become nearly identical across the batch, which makes
+    its train-mode BatchNorm (statistics over B samples) amplify rounding noise by 1/sqrt(var)
+    -- an ill-conditioned test problem rather than a property of real speech batches."""
+    import numpy as np
+    rs = np.random.RandomState(seed)
+    t = np.arange(T, dtype=np.float64)[:, None]
+    f = np.arange(80, dtype=np.float64)[None, :]
+    out = np.zeros((B, T, 80))
+    for b in range(B):
+        f0 = 6.0 + 9.0 * b + 3.0 * rs.rand()                       # ridge spacing (Mel bins)
+        mod = 0.05 + 0.04 * b                                       # temporal modulation rate
+        ridges = np.cos(2 * np.pi * f / f0 + 0.7 * np.sin(2 * np.pi * mod * t))
+        tilt = -(0.4 + 0.3 * b) * (f / 80.0)
+        env = 0.6 + 0.4 * np.sin(2 * np.pi * (0.011 + 0.007 * b) * t + b)
+        out[b] = env * ridges + tilt + (0.25 + 0.1 * b) * rs.standard_normal((T, 80))
+    return torch.from_numpy(out.astype("float32"))

@@ -64,8 +64,9 @@ def sub(t, n=2048):
 def convae_fixture(tag, B, T, seed, recon_kind):
     from models.ConvAutoEncoder import ConvAutoencoder as RefAE
     params = O.numpy_params(8886)
+    from oracle.features import synthetic_feats
     rs = np.random.RandomState(seed)
-    feats = torch.from_numpy(rs.standard_normal((B, T, 80)).astype("float32"))
+    feats = synthetic_feats(B, T, seed)
     feats[-1, T - 5:] = 0.0                                # a few zero-padded frames
     target = feats + torch.from_numpy(0.1 * rs.standard_normal((B, T, 80)).astype("float32"))
     gender = torch.arange(B) % 2
@@ -190,7 +191,7 @@ if __name__ == "__main__":
     sys.path.insert(0, REF)
     torch.manual_seed(0)
     torch.set_num_threads(1)        # deterministic CPU reductions
-    convae_fixture("S", B=2, T=72, seed=1, recon_kind="l1")
-    convae_fixture("S_mse", B=3, T=36, seed=2, recon_kind="mse")
+    convae_fixture("S", B=4, T=72, seed=1, recon_kind="l1")
+    convae_fixture("S_mse", B=5, T=36, seed=2, recon_kind="mse")
     loss_fixtures()
     data_pins()

@@ -1,0 +1,364 @@
+"""ConvAutoencoder: drop-in for ``models.ConvAutoEncoder.ConvAutoencoder`` of the reference
+(models/ConvAutoEncoder.py:136-200) with the whole forward + backward on libsa_hip.so.
+
+Same constructor (no arguments needed), same ``forward(feats[B,T,80]) -> (recon[B,T,80],
+log_probs[B,2])``, same parameter / buffer names and shapes (``encoder.0.weight`` ...
+``sex_classifier.classify.6.bias``; the torch.nn layers below are used ONLY as parameter
+containers so that ``state_dict()``, ``named_parameters()`` with the reference's
+``"sex_classifier" in name`` freeze logic, and default initialisation are the reference's).
+Their ``forward`` is never called: one ``torch.autograd.Function`` runs the fused pipeline
+  - activations channels-last [B, L, C] in ``dtype`` (bf16 default, fp32 available),
+  - InstanceNorm / BatchNorm statistics from the producing conv's epilogue, normalisation +
+    x*sigmoid(x) applied in the consumer's prologue (the normalised tensors are never stored),
+  - GradReverse folded into the first classifier BatchNorm's backward coefficients,
+  - the reshape-not-transpose before StatisticsPooling (models/ConvAutoEncoder.py:61).
+"""
+import torch
+import torch.nn as nn
+
+from . import ops
+from ._lib import SaHipError
+
+K5 = 5
+CONVT_WG_TAPS = [(1, 0), (1, 1), (0, 0), (0, 1), (-1, 0)]      # (input row offset, output phase) per tap
+
+
+class _ParamOnly(nn.Module):
+    """activation placeholders keep the Sequential indices of the reference."""
+
+    def forward(self, x):                                        # pragma: no cover
+        raise SaHipError("parameter container only; use ConvAutoencoder.forward")
+
+
+class GLU(_ParamOnly):
+    pass
+
+
+class StatisticsPooling(_ParamOnly):
+    pass
+
+
+class TDNNSexClassifier(nn.Module):
+    def __init__(self, num_classes=2):
+        super().__init__()
+        self.tdnn = nn.Sequential(
+            nn.Conv1d(128, 128, kernel_size=5, dilation=1), nn.ReLU(), nn.BatchNorm1d(128),
+            nn.Conv1d(128, 128, kernel_size=3, dilation=2), nn.ReLU(), nn.BatchNorm1d(128),
+            nn.Conv1d(128, 128, kernel_size=3, dilation=3), nn.ReLU(), nn.BatchNorm1d(128),
+        )
+        self.norm = nn.BatchNorm1d(128)
+        self.stats_pooling = StatisticsPooling()
+        self.classify = nn.Sequential(
+            nn.Linear(256, 128), nn.ReLU(), nn.BatchNorm1d(128),
+            nn.Linear(128, 64), nn.ReLU(), nn.BatchNorm1d(64),
+            nn.Linear(64, num_classes),
+        )
+
+    def forward(self, x):                                        # pragma: no cover
+        raise SaHipError("parameter container only; use ConvAutoencoder.forward")
+
+
+class ConvAutoencoder(nn.Module):
+    def __init__(self, dtype=torch.bfloat16, pooling_noise=True, sync_bn=True):
+        super().__init__()
+        self.encoder = nn.Sequential(
+            nn.Conv1d(1, 32, 15, 1, 7), GLU(),
+            nn.Conv1d(32, 64, 5, 2, 2), nn.InstanceNorm1d(64, affine=True), GLU(),
+            nn.Conv1d(64, 64, 5, 1, 2), nn.InstanceNorm1d(64, affine=True), GLU(),
+            nn.Conv1d(64, 128, 5, 2, 2), nn.InstanceNorm1d(128, affine=True), GLU(),
+            nn.Conv1d(128, 128, 5, 1, 2), nn.InstanceNorm1d(128, affine=True), GLU(),
+        )
+        self.decoder = nn.Sequential(
+            nn.Conv1d(128, 128, 5, 1, 2),
+            nn.ConvTranspose1d(128, 64, 5, 2, 2, output_padding=1),
+            nn.InstanceNorm1d(64, affine=True), GLU(),
+            nn.Conv1d(64, 64, 5, 1, 2),
+            nn.ConvTranspose1d(64, 32, 5, 2, 2, output_padding=1),
+            nn.InstanceNorm1d(32, affine=True), GLU(),
+            nn.Conv1d(32, 1, 15, 1, 7),
+        )
+        self.sex_classifier = TDNNSexClassifier(2)
+        self.act_dtype = dtype
+        # speechbrain's StatisticsPooling adds eps*U[1,9] to the pooled mean on every call
+        # (train and eval); True reproduces that, a tensor [B,128] in [0,1] fixes the draw
+        # (tests), False/None gives the deterministic form the oracle uses.
+        self.pooling_noise = pooling_noise
+        self.sync_bn = sync_bn
+
+    def forward(self, feats):
+        names, params = zip(*self.named_parameters())
+        return _ConvAEFn.apply(self, names, feats, *params)
+
+    # ---- SyncBatchNorm support: statistics sums are all-reduced across data-parallel ranks
+    # (what speechbrain's Brain applies under DDP); identity on one process.
+    def _bn_allreduce(self, sums):
+        import torch.distributed as dist
+        if self.sync_bn and dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+            dist.all_reduce(sums)
+            return dist.get_world_size()
+        return 1
+
+
+def _noise(model, B, device):
+    n = model.pooling_noise
+    if n is None or n is False:
+        return None
+    if torch.is_tensor(n):
+        return n.to(device=device, dtype=torch.float32).contiguous()
+    g = torch.randn(B, 128, device=device)                      # speechbrain _get_gauss_noise
+    g = g - g.min()
+    return (g / g.max()).contiguous()
+
+
+class _ConvAEFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, model, names, feats, *params):
+        P = dict(zip(names, params))
+        dt = model.act_dtype
+        train = model.training
+        B, T, Fd = feats.shape
+        Ltot = T * Fd
+        if Fd != 80 or Ltot % 4:
+            raise SaHipError("ConvAutoencoder expects feats [B, T, 80] with T*80 divisible by 4")
+        if not feats.is_cuda:
+            raise SaHipError("ConvAutoencoder runs on the GPU only (no CPU fallback)")
+        L2, L4 = Ltot // 2, Ltot // 4
+        S = {}                                                  # saved for backward
+        x0 = feats.detach().reshape(B, Ltot).contiguous().float()
+        pw = lambda k, kind: ops.pack_weights(P[k], kind, dt)
+
+        def inorm(stats, n, prefix, C):
+            sums = ops.sum_partials(stats, B)
+            return ops.fin_in_fwd(sums, B, C, n, P[prefix + ".weight"], P[prefix + ".bias"])
+
+        def bnorm(sums, count, mod, prefix, C):
+            """sums [C,2] local; returns (mean, rstd, scale, shift) per channel."""
+            if not train:
+                return ops.fin_bn_eval(C, P[prefix + ".weight"], P[prefix + ".bias"],
+                                       mod.running_mean, mod.running_var)
+            w = model._bn_allreduce(sums)
+            out = ops.fin_bn_fwd(sums, C, count * w, P[prefix + ".weight"], P[prefix + ".bias"],
+                                 mod.running_mean, mod.running_var)
+            mod.num_batches_tracked += 1
+            return out
+
+        enc, dec, cls = model.encoder, model.decoder, model.sex_classifier
+        # ---------------- encoder ----------------
+        y0 = ops.conv1toC(x0, P["encoder.0.weight"], P["encoder.0.bias"], dt)
+        y1, st = ops.conv_gemm(y0, pw("encoder.2.weight", "conv_fwd"), P["encoder.2.bias"], 32, 64, 2, 1,
+                               ops.taps_conv(K5, 1, 2), L2, swish=True, want_stats=True)
+        n1 = inorm(st, L2, "encoder.3", 64)
+        y2, st = ops.conv_gemm(y1, pw("encoder.5.weight", "conv_fwd"), P["encoder.5.bias"], 64, 64, 1, 1,
+                               ops.taps_conv(K5, 1, 2), L2, s1=n1[2], t1=n1[3], swish=True, want_stats=True)
+        n2 = inorm(st, L2, "encoder.6", 64)
+        y3, st = ops.conv_gemm(y2, pw("encoder.8.weight", "conv_fwd"), P["encoder.8.bias"], 64, 128, 2, 1,
+                               ops.taps_conv(K5, 1, 2), L4, s1=n2[2], t1=n2[3], swish=True, want_stats=True)
+        n3 = inorm(st, L4, "encoder.9", 128)
+        y4, st = ops.conv_gemm(y3, pw("encoder.11.weight", "conv_fwd"), P["encoder.11.bias"], 128, 128, 1, 1,
+                               ops.taps_conv(K5, 1, 2), L4, s1=n3[2], t1=n3[3], swish=True, want_stats=True)
+        n4 = inorm(st, L4, "encoder.12", 128)
+        # ---------------- sex classifier (GradReverse = identity forward) ----------------
+        sums = ops.sum_partials(ops.act_stats(y4, n4[2], n4[3], True), 1) if train else None
+        bn_n = bnorm(sums, B * L4, cls.norm, "sex_classifier.norm", 128)
+        La, Lb, Lc = L4 - 4, L4 - 8, L4 - 14
+        r0, st = ops.conv_gemm(y4, pw("sex_classifier.tdnn.0.weight", "conv_fwd"),
+                               P["sex_classifier.tdnn.0.bias"], 128, 128, 1, 1, ops.taps_conv(5, 1, 0), La,
+                               s1=n4[2], t1=n4[3], swish=True, s2=bn_n[2], t2=bn_n[3], relu=True,
+                               want_stats=True)
+        bn0 = bnorm(ops.sum_partials(st, 1), B * La, cls.tdnn[2], "sex_classifier.tdnn.2", 128)
+        r1, st = ops.conv_gemm(r0, pw("sex_classifier.tdnn.3.weight", "conv_fwd"),
+                               P["sex_classifier.tdnn.3.bias"], 128, 128, 1, 1, ops.taps_conv(3, 2, 0), Lb,
+                               s2=bn0[2], t2=bn0[3], relu=True, want_stats=True)
+        bn1 = bnorm(ops.sum_partials(st, 1), B * Lb, cls.tdnn[5], "sex_classifier.tdnn.5", 128)
+        r2, st = ops.conv_gemm(r1, pw("sex_classifier.tdnn.6.weight", "conv_fwd"),
+                               P["sex_classifier.tdnn.6.bias"], 128, 128, 1, 1, ops.taps_conv(3, 3, 0), Lc,
+                               s2=bn1[2], t2=bn1[3], relu=True, want_stats=True)
+        bn2 = bnorm(ops.sum_partials(st, 1), B * Lc, cls.tdnn[8], "sex_classifier.tdnn.8", 128)
+        pooled, pmean, psd = ops.pool_fwd(r2, bn2[2], bn2[3], noise=_noise(model, B, feats.device))
+        H1 = ops.dense(pooled, P["sex_classifier.classify.0.weight"], P["sex_classifier.classify.0.bias"],
+                       128, 256, relu=True)
+        f1 = bnorm(ops.colsums(H1) if train else None, B, cls.classify[2], "sex_classifier.classify.2", 128)
+        H2 = ops.dense(H1, P["sex_classifier.classify.3.weight"], P["sex_classifier.classify.3.bias"],
+                       64, 128, ps=f1[2], pt=f1[3], relu=True)
+        f2 = bnorm(ops.colsums(H2) if train else None, B, cls.classify[5], "sex_classifier.classify.5", 64)
+        logits = ops.dense(H2, P["sex_classifier.classify.6.weight"], P["sex_classifier.classify.6.bias"],
+                           2, 64, ps=f2[2], pt=f2[3])
+        logp = ops.log_softmax(logits)
+        # ---------------- decoder ----------------
+        y5 = ops.conv_gemm(y4, pw("decoder.0.weight", "conv_fwd"), P["decoder.0.bias"], 128, 128, 1, 1,
+                           ops.taps_conv(K5, 1, 2), L4, s1=n4[2], t1=n4[3], swish=True)
+        y6, st = ops.conv_gemm(y5, pw("decoder.1.weight", "convT_fwd"), P["decoder.1.bias"], 128, 64, 1, 2,
+                               ops.UP2, L2, want_stats=True)
+        n6 = inorm(st, L2, "decoder.2", 64)
+        y7 = ops.conv_gemm(y6, pw("decoder.4.weight", "conv_fwd"), P["decoder.4.bias"], 64, 64, 1, 1,
+                           ops.taps_conv(K5, 1, 2), L2, s1=n6[2], t1=n6[3], swish=True)
+        y8, st = ops.conv_gemm(y7, pw("decoder.5.weight", "convT_fwd"), P["decoder.5.bias"], 64, 32, 1, 2,
+                               ops.UP2, Ltot, want_stats=True)
+        n8 = inorm(st, Ltot, "decoder.6", 32)
+        recon = ops.convCto1(y8, P["decoder.8.weight"], P["decoder.8.bias"], n8[2], n8[3], True)
+
+        S.update(x0=x0, y=[y0, y1, y2, y3, y4, y5, y6, y7, y8], r=[r0, r1, r2],
+                 n=[None, n1, n2, n3, n4, None, n6, None, n8], bn=[bn_n, bn0, bn1, bn2], f=[f1, f2],
+                 pooled=pooled, pmean=pmean, psd=psd, H1=H1, H2=H2, logp=logp,
+                 dims=(B, T, Ltot, L2, L4, La, Lb, Lc), train=train)
+        ctx.S, ctx.model, ctx.names, ctx.params = S, model, names, params
+        ctx.need_input_grad = feats.requires_grad
+        return recon.view(B, T, Fd), logp
+
+    @staticmethod
+    def backward(ctx, d_recon, d_logp):
+        S, model, names = ctx.S, ctx.model, ctx.names
+        if S is None:
+            raise SaHipError("ConvAutoencoder backward called twice (saved tensors were released)")
+        P = dict(zip(names, ctx.params))
+        dt = model.act_dtype
+        B, T, Ltot, L2, L4, La, Lb, Lc = S["dims"]
+        if not S["train"]:
+            raise SaHipError("backward through eval-mode BatchNorm is not implemented")
+        y0, y1, y2, y3, y4, y5, y6, y7, y8 = S["y"]
+        r0, r1, r2 = S["r"]
+        n1, n2, n3, n4, n6, n8 = S["n"][1], S["n"][2], S["n"][3], S["n"][4], S["n"][6], S["n"][8]
+        bn_n, bn0, bn1, bn2 = S["bn"]
+        f1, f2 = S["f"]
+        dev = y0.device
+        G = {k: None for k in names}
+        need = {k: p.requires_grad for k, p in P.items()}
+        newg = lambda k: torch.empty_like(P[k])
+        pw = lambda k, kind: ops.pack_weights(P[k], kind, dt)
+
+        def bias_from(stats, key, C):
+            if need[key]:
+                G[key] = ops.fin_bias(ops.sum_partials(stats, B), B, C, newg(key))
+
+        def in_block(g, y, nrm, C, Ln, prefix, bias_key, g2=None):
+            """backward of [conv -> InstanceNorm(prefix) -> swish] w.r.t. the conv output y."""
+            mean, rstd, scale, shift = nrm
+            st = ops.ew("stats", g, y, C, out=g, g2=g2, s1=scale, t1=shift, mean=mean, rstd=rstd, actbwd=True)
+            sums = ops.sum_partials(st, B)
+            dg, db = newg(prefix + ".weight"), newg(prefix + ".bias")
+            c1, c2, c3 = ops.fin_norm_bwd(sums, sums, B * C, C, Ln, P[prefix + ".weight"], mean, rstd,
+                                          dgamma=dg, dbeta=db)
+            G[prefix + ".weight"], G[prefix + ".bias"] = dg, db
+            st2 = ops.ew("apply", g, y, C, out=g, c1=c1, c2=c2, c3=c3)
+            bias_from(st2, bias_key, C)
+            return g                                             # now d y
+
+        def bn_block(g, r, bn, Ln, prefix, bias_key, xp=None):
+            """backward of [conv -> ReLU -> BatchNorm(prefix)] w.r.t. the conv output (stored r =
+            relu output); xp=(s1,t1): the BN input is swish(r*s1+t1) instead (the `norm` BN on the
+            encoder output, with GradReverse in front: sign -1, no ReLU mask)."""
+            mean, rstd = bn[0], bn[1]
+            kw = dict(s1=xp[0], t1=xp[1], xp_is_act=True) if xp else {}
+            st = ops.ew("stats", g, r, 128, mean=mean, rstd=rstd, per_c=True, **kw)
+            lsums = ops.sum_partials(st, 1)
+            gsums = lsums.clone()
+            w = model._bn_allreduce(gsums)
+            dg, db = newg(prefix + ".weight"), newg(prefix + ".bias")
+            c1, c2, c3 = ops.fin_norm_bwd(gsums, lsums, 128, 128, float(B * Ln * w), P[prefix + ".weight"],
+                                          mean, rstd, sign=-1.0 if xp else 1.0, dgamma=dg, dbeta=db)
+            G[prefix + ".weight"], G[prefix + ".bias"] = dg, db
+            st2 = ops.ew("apply", g, r, 128, out=g, c1=c1, c2=c2, c3=c3, relu_mask=not xp, per_c=True,
+                         want_stats=bias_key is not None, **kw)
+            if bias_key:
+                bias_from(st2, bias_key, 128)
+            return g
+
+        def conv_wgrad(key, x, dy, cin, cout, sa, Mrows, K, dil, pad, **pro):
+            if need[key]:
+                G[key] = ops.wgrad(x, dy, cin, cout, sa, 1, [(k * dil - pad, 0) for k in range(K)], Mrows,
+                                   newg(key), (K, cin * K, 1), **pro)
+
+        def convT_wgrad(key, x, dy, cin, cout, Mrows):
+            if need[key]:
+                G[key] = ops.wgrad(x, dy, cin, cout, 1, 2, CONVT_WG_TAPS, Mrows, newg(key), (cout * K5, K5, 1))
+
+        # ======================= decoder =======================
+        if d_recon is None:
+            d_recon = torch.zeros(B, T, 80, device=dev)
+        if d_logp is None:
+            d_logp = torch.zeros(B, 2, device=dev)
+        g_rec = d_recon.reshape(B, Ltot).contiguous().float()
+        if need["decoder.8.bias"]:
+            G["decoder.8.bias"] = ops.sum_partials(g_rec, 1, n=80).sum().float().view(1)
+        if need["decoder.8.weight"]:
+            G["decoder.8.weight"] = ops.wgrad1C(g_rec, y8, newg("decoder.8.weight"), flip=True,
+                                                s1=n8[2], t1=n8[3], swish=True)
+        g = ops.conv1toC(g_rec, P["decoder.8.weight"], None, dt, flip=True)                # d a8
+        g = in_block(g, y8, n8, 32, Ltot, "decoder.6", "decoder.5.bias")                    # d y8
+        convT_wgrad("decoder.5.weight", y7, g, 64, 32, L2)
+        g, st = ops.conv_gemm(g, pw("decoder.5.weight", "convT_dgrad"), None, 32, 64, 2, 1,
+                              ops.taps_convT_dgrad(), L2, want_stats=True)                   # d y7
+        bias_from(st, "decoder.4.bias", 64)
+        conv_wgrad("decoder.4.weight", y6, g, 64, 64, 1, L2, K5, 1, 2, s1=n6[2], t1=n6[3], swish=True)
+        g = ops.conv_gemm(g, pw("decoder.4.weight", "conv_dgrad"), None, 64, 64, 1, 1,
+                          ops.taps_conv_dgrad_s1(K5, 1, 2), L2)                              # d a6
+        g = in_block(g, y6, n6, 64, L2, "decoder.2", "decoder.1.bias")                      # d y6
+        convT_wgrad("decoder.1.weight", y5, g, 128, 64, L4)
+        g, st = ops.conv_gemm(g, pw("decoder.1.weight", "convT_dgrad"), None, 64, 128, 2, 1,
+                              ops.taps_convT_dgrad(), L4, want_stats=True)                   # d y5
+        bias_from(st, "decoder.0.bias", 128)
+        conv_wgrad("decoder.0.weight", y4, g, 128, 128, 1, L4, K5, 1, 2, s1=n4[2], t1=n4[3], swish=True)
+        da4_dec = ops.conv_gemm(g, pw("decoder.0.weight", "conv_dgrad"), None, 128, 128, 1, 1,
+                                ops.taps_conv_dgrad_s1(K5, 1, 2), L4)
+
+        # ======================= sex classifier =======================
+        c = "sex_classifier.classify."
+        dLG = ops.log_softmax_bwd(d_logp.contiguous().float(), S["logp"])
+        H1, H2 = S["H1"], S["H2"]
+        G[c + "6.weight"] = ops.dense_wgrad(dLG, H2, newg(c + "6.weight"), ps=f2[2], pt=f2[3])
+        G[c + "6.bias"] = ops.colsums(dLG)[:, 0].float()
+        dN2 = ops.dense(dLG, P[c + "6.weight"], None, 64, 2, transpose_w=True)
+        l2 = ops.colsums(dN2, H2, f2[0], f2[1]); g2s = l2.clone(); w = model._bn_allreduce(g2s)
+        G[c + "5.weight"], G[c + "5.bias"] = l2[:, 1].float(), l2[:, 0].float()
+        dH2 = ops.bn2d_bwd(dN2, H2, g2s, B * w, P[c + "5.weight"], f2[0], f2[1], True)
+        G[c + "3.weight"] = ops.dense_wgrad(dH2, H1, newg(c + "3.weight"), ps=f1[2], pt=f1[3])
+        G[c + "3.bias"] = ops.colsums(dH2)[:, 0].float()
+        dN1 = ops.dense(dH2, P[c + "3.weight"], None, 128, 64, transpose_w=True)
+        l1 = ops.colsums(dN1, H1, f1[0], f1[1]); g1s = l1.clone(); w = model._bn_allreduce(g1s)
+        G[c + "2.weight"], G[c + "2.bias"] = l1[:, 1].float(), l1[:, 0].float()
+        dH1 = ops.bn2d_bwd(dN1, H1, g1s, B * w, P[c + "2.weight"], f1[0], f1[1], True)
+        G[c + "0.weight"] = ops.dense_wgrad(dH1, S["pooled"], newg(c + "0.weight"))
+        G[c + "0.bias"] = ops.colsums(dH1)[:, 0].float()
+        dP = ops.dense(dH1, P[c + "0.weight"], None, 256, 128, transpose_w=True)
+        t = "sex_classifier.tdnn."
+        g = ops.pool_bwd(r2, bn2[2], bn2[3], dP, S["pmean"], S["psd"])
+        g = bn_block(g, r2, bn2, Lc, t + "8", t + "6.bias")
+        conv_wgrad(t + "6.weight", r1, g, 128, 128, 1, Lc, 3, 3, 0, s2=bn1[2], t2=bn1[3])
+        g = ops.conv_gemm(g, pw(t + "6.weight", "conv_dgrad"), None, 128, 128, 1, 1,
+                          ops.taps_conv_dgrad_s1(3, 3, 0), Lb)
+        g = bn_block(g, r1, bn1, Lb, t + "5", t + "3.bias")
+        conv_wgrad(t + "3.weight", r0, g, 128, 128, 1, Lb, 3, 2, 0, s2=bn0[2], t2=bn0[3])
+        g = ops.conv_gemm(g, pw(t + "3.weight", "conv_dgrad"), None, 128, 128, 1, 1,
+                          ops.taps_conv_dgrad_s1(3, 2, 0), La)
+        g = bn_block(g, r0, bn0, La, t + "2", t + "0.bias")
+        conv_wgrad(t + "0.weight", y4, g, 128, 128, 1, La, 5, 1, 0, s1=n4[2], t1=n4[3], swish=True,
+                   s2=bn_n[2], t2=bn_n[3])
+        g = ops.conv_gemm(g, pw(t + "0.weight", "conv_dgrad"), None, 128, 128, 1, 1,
+                          ops.taps_conv_dgrad_s1(5, 1, 0), L4)
+        da4_cls = bn_block(g, y4, bn_n, L4, "sex_classifier.norm", None, xp=(n4[2], n4[3]))   # includes GRL
+
+        # ======================= encoder =======================
+        g = in_block(da4_dec, y4, n4, 128, L4, "encoder.12", "encoder.11.bias", g2=da4_cls)  # d y4
+        conv_wgrad("encoder.11.weight", y3, g, 128, 128, 1, L4, K5, 1, 2, s1=n3[2], t1=n3[3], swish=True)
+        g = ops.conv_gemm(g, pw("encoder.11.weight", "conv_dgrad"), None, 128, 128, 1, 1,
+                          ops.taps_conv_dgrad_s1(K5, 1, 2), L4)
+        g = in_block(g, y3, n3, 128, L4, "encoder.9", "encoder.8.bias")                      # d y3
+        conv_wgrad("encoder.8.weight", y2, g, 64, 128, 2, L4, K5, 1, 2, s1=n2[2], t1=n2[3], swish=True)
+        g = ops.conv_gemm(g, pw("encoder.8.weight", "conv_dgrad"), None, 128, 64, 1, 2, ops.UP2, L2)
+        g = in_block(g, y2, n2, 64, L2, "encoder.6", "encoder.5.bias")                       # d y2
+        conv_wgrad("encoder.5.weight", y1, g, 64, 64, 1, L2, K5, 1, 2, s1=n1[2], t1=n1[3], swish=True)
+        g = ops.conv_gemm(g, pw("encoder.5.weight", "conv_dgrad"), None, 64, 64, 1, 1,
+                          ops.taps_conv_dgrad_s1(K5, 1, 2), L2)
+        g = in_block(g, y1, n1, 64, L2, "encoder.3", "encoder.2.bias")                       # d y1
+        conv_wgrad("encoder.2.weight", y0, g, 32, 64, 2, L2, K5, 1, 2, swish=True)
+        g = ops.conv_gemm(g, pw("encoder.2.weight", "conv_dgrad"), None, 64, 32, 1, 2, ops.UP2, Ltot)
+        st = ops.ew("stats", g, y0, 32, out=g, actbwd=True)                                  # d y0
+        bias_from(st, "encoder.0.bias", 32)
+        if need["encoder.0.weight"]:
+            G["encoder.0.weight"] = ops.wgrad1C(S["x0"], g, newg("encoder.0.weight"))
+        d_feats = None
+        if ctx.need_input_grad:
+            d_feats = ops.convCto1(g, P["encoder.0.weight"], None, flip=True).view(B, T, 80)
+        ctx.S = None
+        grads = tuple(G[k] if need[k] else None for k in names)
+        return (None, None, d_feats) + grads

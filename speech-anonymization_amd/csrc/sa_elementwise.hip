@@ -188,18 +188,18 @@ extern "C" int sa_act_stats(int dtype, int C, const void* x, const float* s1, co
 // ---------------------------------------------------------------------------------
 // batched slab sum: dst[bb][i] = sum_k slabs[bb][k][i]   (fixed order, double accumulate)
 // ---------------------------------------------------------------------------------
-__global__ void sa_sum_partials_kernel(const float* __restrict__ slabs, float* __restrict__ dst,
+__global__ void sa_sum_partials_kernel(const float* __restrict__ slabs, double* __restrict__ dst,
                                        int nslab, int n) {
   const int bb = blockIdx.y;
   for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
     double s = 0.0;
     const float* p = slabs + (size_t)bb * nslab * n + i;
     for (int k = 0; k < nslab; ++k) s += (double)p[(size_t)k * n];
-    dst[(size_t)bb * n + i] = (float)s;
+    dst[(size_t)bb * n + i] = s;
   }
 }
 
-extern "C" int sa_sum_partials(const float* slabs, float* dst, int nbatch, int nslab, int n,
+extern "C" int sa_sum_partials(const float* slabs, double* dst, int nbatch, int nslab, int n,
                                void* stream) {
   if (!slabs || !dst || nbatch <= 0 || nslab <= 0 || n <= 0) return -22;
   hipLaunchKernelGGL(sa_sum_partials_kernel, dim3(sa_div_up(n, 256), nbatch), dim3(256), 0,
@@ -212,7 +212,7 @@ extern "C" int sa_sum_partials(const float* slabs, float* dst, int nbatch, int n
 // finalisers.  sums layouts: IN  [B][C][2],  BN  [C][2]  (sum, sumsq) or (S1, S2).
 // ---------------------------------------------------------------------------------
 // InstanceNorm forward: mean, rstd, scale = gamma*rstd, shift = beta - mean*scale per (b,c)
-__global__ void sa_fin_in_fwd_kernel(const float* __restrict__ sums, int BC, int C, float n,
+__global__ void sa_fin_in_fwd_kernel(const double* __restrict__ sums, int BC, int C, float n,
                                      const float* __restrict__ gamma, const float* __restrict__ beta,
                                      float eps, float* mean, float* rstd, float* scale, float* shift) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -225,7 +225,7 @@ __global__ void sa_fin_in_fwd_kernel(const float* __restrict__ sums, int BC, int
   mean[i] = (float)m; rstd[i] = r; scale[i] = sc; shift[i] = beta[i % C] - (float)m * sc;
 }
 
-extern "C" int sa_fin_in_fwd(const float* sums, int B, int C, int n, const float* gamma,
+extern "C" int sa_fin_in_fwd(const double* sums, int B, int C, int n, const float* gamma,
                              const float* beta, float eps, float* mean, float* rstd, float* scale,
                              float* shift, void* stream) {
   if (!sums || !gamma || !beta || !mean || !rstd || !scale || !shift) return -22;
@@ -238,7 +238,7 @@ extern "C" int sa_fin_in_fwd(const float* sums, int B, int C, int n, const float
 
 // BatchNorm (train mode) forward from (possibly all-reduced) sums over `count` elements per
 // channel; updates running_mean / running_var (unbiased) with `momentum` like nn.BatchNorm1d.
-__global__ void sa_fin_bn_fwd_kernel(const float* __restrict__ sums, int C, double count,
+__global__ void sa_fin_bn_fwd_kernel(const double* __restrict__ sums, int C, double count,
                                      const float* __restrict__ gamma, const float* __restrict__ beta,
                                      float eps, float momentum, float* run_mean, float* run_var,
                                      float* mean, float* rstd, float* scale, float* shift) {
@@ -257,7 +257,7 @@ __global__ void sa_fin_bn_fwd_kernel(const float* __restrict__ sums, int C, doub
   }
 }
 
-extern "C" int sa_fin_bn_fwd(const float* sums, int C, double count, const float* gamma,
+extern "C" int sa_fin_bn_fwd(const double* sums, int C, double count, const float* gamma,
                              const float* beta, float eps, float momentum, float* run_mean,
                              float* run_var, float* mean, float* rstd, float* scale, float* shift,
                              void* stream) {
@@ -269,12 +269,33 @@ extern "C" int sa_fin_bn_fwd(const float* sums, int C, double count, const float
   return e == hipSuccess ? 0 : -(int)e;
 }
 
+// BatchNorm in eval mode: normalise with the running statistics.
+__global__ void sa_fin_bn_eval_kernel(int C, const float* __restrict__ gamma, const float* __restrict__ beta,
+                                      float eps, const float* __restrict__ rm, const float* __restrict__ rv,
+                                      float* mean, float* rstd, float* scale, float* shift) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= C) return;
+  const float r = 1.0f / sqrtf(rv[i] + eps), sc = gamma[i] * r;
+  mean[i] = rm[i]; rstd[i] = r; scale[i] = sc; shift[i] = beta[i] - rm[i] * sc;
+}
+
+extern "C" int sa_fin_bn_eval(int C, const float* gamma, const float* beta, float eps,
+                              const float* run_mean, const float* run_var, float* mean, float* rstd,
+                              float* scale, float* shift, void* stream) {
+  if (!gamma || !beta || !run_mean || !run_var || !mean || !rstd || !scale || !shift) return -22;
+  hipLaunchKernelGGL(sa_fin_bn_eval_kernel, dim3(sa_div_up(C, 128)), dim3(128), 0,
+                     reinterpret_cast<hipStream_t>(stream), C, gamma, beta, eps, run_mean, run_var,
+                     mean, rstd, scale, shift);
+  hipError_t e = hipGetLastError();
+  return e == hipSuccess ? 0 : -(int)e;
+}
+
 // Normalisation backward coefficients.  sums = (S1 = sum g', S2 = sum g'*xhat) per group;
 // groups = B*C (InstanceNorm, n = L) or C (BatchNorm, n = count).
 //   d x = c1*g' + c2*xv + c3,  c1 = gamma*rstd, c2 = -c1*rstd*S2/n, c3 = c1*(-S1/n + mean*rstd*S2/n)
 // sign = -1 folds the GradReverse layer in.  lsums (local sums, may equal sums) feed
 // d gamma = sum_b S2, d beta = sum_b S1 (written, not accumulated, when dgamma != null).
-__global__ void sa_fin_norm_bwd_kernel(const float* __restrict__ sums, const float* __restrict__ lsums,
+__global__ void sa_fin_norm_bwd_kernel(const double* __restrict__ sums, const double* __restrict__ lsums,
                                        int G, int C, double n, const float* __restrict__ gamma,
                                        const float* __restrict__ mean, const float* __restrict__ rstd,
                                        float sign, float* c1, float* c2, float* c3, float* dgamma,
@@ -295,7 +316,7 @@ __global__ void sa_fin_norm_bwd_kernel(const float* __restrict__ sums, const flo
   }
 }
 
-extern "C" int sa_fin_norm_bwd(const float* sums, const float* lsums, int groups, int C, double n,
+extern "C" int sa_fin_norm_bwd(const double* sums, const double* lsums, int groups, int C, double n,
                                const float* gamma, const float* mean, const float* rstd, float sign,
                                float* c1, float* c2, float* c3, float* dgamma, float* dbeta,
                                void* stream) {
@@ -309,7 +330,7 @@ extern "C" int sa_fin_norm_bwd(const float* sums, const float* lsums, int groups
 }
 
 // bias gradient from per-(b,c) sums: db[c] = sum_b sums[b][c][0]
-__global__ void sa_fin_bias_kernel(const float* __restrict__ sums, int B, int C, float* db) {
+__global__ void sa_fin_bias_kernel(const double* __restrict__ sums, int B, int C, float* db) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= C) return;
   double s = 0.0;
@@ -317,7 +338,7 @@ __global__ void sa_fin_bias_kernel(const float* __restrict__ sums, int B, int C,
   db[i] = (float)s;
 }
 
-extern "C" int sa_fin_bias(const float* sums, int B, int C, float* db, void* stream) {
+extern "C" int sa_fin_bias(const double* sums, int B, int C, float* db, void* stream) {
   if (!sums || !db) return -22;
   hipLaunchKernelGGL(sa_fin_bias_kernel, dim3(sa_div_up(C, 128)), dim3(128), 0,
                      reinterpret_cast<hipStream_t>(stream), sums, B, C, db);

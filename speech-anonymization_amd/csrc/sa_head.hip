@@ -83,7 +83,7 @@ extern "C" int sa_pool_fwd(int dtype, const void* r, const float* scale, const f
 
 // sums [B][128][2] -> pooled [B][256] = (mean + eps*((1-9)*noise+9) if noise, std_unbiased + eps)
 // and saves mean / raw std for the backward.
-__global__ void sa_pool_fin_kernel(const float* __restrict__ sums, int B, int n,
+__global__ void sa_pool_fin_kernel(const double* __restrict__ sums, int B, int n,
                                    const float* __restrict__ noise, float eps, float* pooled,
                                    float* mean, float* stdraw) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -101,7 +101,7 @@ __global__ void sa_pool_fin_kernel(const float* __restrict__ sums, int B, int n,
   pooled[(size_t)b * 256 + 128 + j] = sd + eps;
 }
 
-extern "C" int sa_pool_fin(const float* sums, int B, int n, const float* noise, float eps,
+extern "C" int sa_pool_fin(const double* sums, int B, int n, const float* noise, float eps,
                            float* pooled, float* mean, float* stdraw, void* stream) {
   if (!sums || !pooled || !mean || !stdraw || n < 2) return -22;
   hipLaunchKernelGGL(sa_pool_fin_kernel, dim3(sa_div_up(B * 128, 256)), dim3(256), 0,
@@ -230,7 +230,7 @@ extern "C" int sa_dense(const float* X, int lda, const float* ps, const float* p
 // where Xh = X (sumsq, Xh null) or a second matrix (e.g. normalised activations).
 __global__ void sa_colsums_kernel(const float* __restrict__ X, const float* __restrict__ H,
                                   const float* __restrict__ hm, const float* __restrict__ hr,
-                                  int M, int N, float* sums) {
+                                  int M, int N, double* sums) {
   const int n = blockIdx.x * blockDim.x + threadIdx.x;
   if (n >= N) return;
   double s = 0.0, q = 0.0;
@@ -240,11 +240,11 @@ __global__ void sa_colsums_kernel(const float* __restrict__ X, const float* __re
     if (hm) h = (h - hm[n]) * hr[n];
     s += x; q += (double)x * h;
   }
-  sums[2 * n] = (float)s; sums[2 * n + 1] = (float)q;
+  sums[2 * n] = s; sums[2 * n + 1] = q;
 }
 
 extern "C" int sa_colsums(const float* X, const float* H, const float* hmean, const float* hrstd,
-                          int M, int N, float* sums, void* stream) {
+                          int M, int N, double* sums, void* stream) {
   if (!X || !sums) return -22;
   hipLaunchKernelGGL(sa_colsums_kernel, dim3(sa_div_up(N, 64)), dim3(64), 0,
                      reinterpret_cast<hipStream_t>(stream), X, H, hmean, hrstd, M, N, sums);
@@ -255,7 +255,7 @@ extern "C" int sa_colsums(const float* X, const float* H, const float* hmean, co
 // BatchNorm backward on a small [M][N] activation (batch statistics over `count` rows,
 // possibly global): dH = gamma*rstd*(G - S1/count - hhat*S2/count) [* (H > 0)]
 __global__ void sa_bn2d_bwd_kernel(const float* __restrict__ G, const float* __restrict__ H,
-                                   const float* __restrict__ sums, double count,
+                                   const double* __restrict__ sums, double count,
                                    const float* __restrict__ gamma, const float* __restrict__ mean,
                                    const float* __restrict__ rstd, int relu_mask, int M, int N,
                                    float* dH) {
@@ -268,7 +268,7 @@ __global__ void sa_bn2d_bwd_kernel(const float* __restrict__ G, const float* __r
   dH[i] = v;
 }
 
-extern "C" int sa_bn2d_bwd(const float* G, const float* H, const float* sums, double count,
+extern "C" int sa_bn2d_bwd(const float* G, const float* H, const double* sums, double count,
                            const float* gamma, const float* mean, const float* rstd, int relu_mask,
                            int M, int N, float* dH, void* stream) {
   if (!G || !H || !sums || !gamma || !mean || !rstd || !dH) return -22;

@@ -87,14 +87,16 @@ extern "C" int sa_conv1toC(int dtype, const float* x, const float* w, const floa
 }
 
 // y[b][l] = bias + sum_k sum_c P(x[b][l+k-7][c]) * w[c][k]       (x T, y fp32)
-// P = prologue: v*s1[b][c]+t1[b][c], then x*sigmoid(x) if swish.   decoder.8 forward.
+// P = prologue: v*s1[b][c]+t1[b][c], then x*sigmoid(x) if swish.   decoder.8 forward
+// (flip=0) and encoder.0 dgrad (flip=1: taps reversed).
 template <typename T>
 __global__ __launch_bounds__(256) void sa_convCto1_kernel(const T* __restrict__ x,
                                                           const float* __restrict__ w,
                                                           const float* __restrict__ bias,
                                                           float* __restrict__ y, int L,
                                                           const float* __restrict__ s1,
-                                                          const float* __restrict__ t1, int swish) {
+                                                          const float* __restrict__ t1, int swish,
+                                                          int flip) {
   constexpr int VEC = Tr<T>::VEC, CH = SA_C32 / VEC, RPP = 256 / CH, TILE = 256, PITCH = 36;
   __shared__ __attribute__((aligned(16))) float xs[(TILE + SA_K15 - 1) * PITCH];
   __shared__ __attribute__((aligned(16))) float ws[SA_K15][SA_C32];
@@ -126,7 +128,7 @@ __global__ __launch_bounds__(256) void sa_convCto1_kernel(const T* __restrict__ 
     }
     for (int i = tid; i < SA_K15 * SA_C32; i += 256) {
       const int k = i / SA_C32, cc = i % SA_C32;
-      ws[k][cc] = w[cc * SA_K15 + k];
+      ws[k][cc] = w[cc * SA_K15 + (flip ? SA_K15 - 1 - k : k)];
     }
   }
   __syncthreads();
@@ -149,17 +151,17 @@ __global__ __launch_bounds__(256) void sa_convCto1_kernel(const T* __restrict__ 
 }
 
 extern "C" int sa_convCto1(int dtype, const void* x, const float* w, const float* bias, float* y,
-                           int B, int L, const float* s1, const float* t1, int swish,
+                           int B, int L, const float* s1, const float* t1, int swish, int flip,
                            void* stream) {
   if (!x || !w || !y || B <= 0 || L <= 0) return -22;
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   dim3 grid(sa_div_up(L, 256), B);
   if (dtype == SA_BF16)
     hipLaunchKernelGGL(sa_convCto1_kernel<bf16_t>, grid, dim3(256), 0, st,
-                       reinterpret_cast<const bf16_t*>(x), w, bias, y, L, s1, t1, swish);
+                       reinterpret_cast<const bf16_t*>(x), w, bias, y, L, s1, t1, swish, flip);
   else
     hipLaunchKernelGGL(sa_convCto1_kernel<float>, grid, dim3(256), 0, st,
-                       reinterpret_cast<const float*>(x), w, bias, y, L, s1, t1, swish);
+                       reinterpret_cast<const float*>(x), w, bias, y, L, s1, t1, swish, flip);
   hipError_t e = hipGetLastError();
   return e == hipSuccess ? 0 : -(int)e;
 }

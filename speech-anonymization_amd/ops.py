@@ -113,12 +113,12 @@ def conv1toC(x, w, bias, dtype, flip=False, want_stats=False):
     return (y, stats) if want_stats else y
 
 
-def convCto1(x, w, bias, s1=None, t1=None, swish=False):
+def convCto1(x, w, bias, s1=None, t1=None, swish=False, flip=False):
     lib = L.load()
     B, Ln, _ = x.shape
     y = torch.empty(B, Ln, dtype=torch.float32, device=x.device)
     L.check(lib.sa_convCto1(L.dt_code(x.dtype), _f(x), _f(w), _f(bias), _f(y), B, Ln, _f(s1), _f(t1),
-                            int(swish), L.stream()), "sa_convCto1")
+                            int(swish), int(flip), L.stream()), "sa_convCto1")
     return y
 
 
@@ -134,13 +134,15 @@ def wgrad1C(u, v, dst, flip=False, s1=None, t1=None, swish=False, accumulate=Fal
     return dst
 
 
-def sum_partials(part, nbatch):
-    """part [nbatch * nslab, n] (any leading shape) -> [nbatch, n] fixed-order sums."""
+def sum_partials(part, nbatch, n=None):
+    """part [nbatch][nslab][n] (contiguous) -> [nbatch, n] fixed-order sums.  n defaults to the
+    product of the last two dims (the [.., C, 2] layout of the statistics slabs)."""
     lib = L.load()
-    n = part.shape[-2] * part.shape[-1] if part.dim() >= 3 else part.shape[-1]
+    if n is None:
+        n = part.shape[-2] * part.shape[-1]
     total = part.numel()
     nslab = total // (nbatch * n)
-    out = torch.empty(nbatch, n, dtype=torch.float32, device=part.device)
+    out = torch.empty(nbatch, n, dtype=torch.float64, device=part.device)
     L.check(lib.sa_sum_partials(_f(part), _f(out), nbatch, nslab, n, L.stream()), "sa_sum_partials")
     return out
 
@@ -159,6 +161,14 @@ def fin_bn_fwd(sums, Cc, count, gamma, beta, run_mean=None, run_var=None, eps=1e
     L.check(lib.sa_fin_bn_fwd(_f(sums), Cc, C.c_double(count), _f(gamma), _f(beta), C.c_float(eps),
                               C.c_float(momentum), _f(run_mean), _f(run_var), _f(o[0]), _f(o[1]),
                               _f(o[2]), _f(o[3]), L.stream()), "sa_fin_bn_fwd")
+    return o[0], o[1], o[2], o[3]
+
+
+def fin_bn_eval(Cc, gamma, beta, run_mean, run_var, eps=1e-5):
+    lib = L.load()
+    o = torch.empty(4, Cc, dtype=torch.float32, device=gamma.device)
+    L.check(lib.sa_fin_bn_eval(Cc, _f(gamma), _f(beta), C.c_float(eps), _f(run_mean), _f(run_var),
+                               _f(o[0]), _f(o[1]), _f(o[2]), _f(o[3]), L.stream()), "sa_fin_bn_eval")
     return o[0], o[1], o[2], o[3]
 
 
@@ -245,7 +255,7 @@ def dense(X, W, bias, N, K, ps=None, pt=None, relu=False, transpose_w=False):
 def colsums(X, H=None, hmean=None, hrstd=None):
     lib = L.load()
     M, N = X.shape
-    s = torch.empty(N, 2, dtype=torch.float32, device=X.device)
+    s = torch.empty(N, 2, dtype=torch.float64, device=X.device)
     L.check(lib.sa_colsums(_f(X), _f(H), _f(hmean), _f(hrstd), M, N, _f(s), L.stream()), "sa_colsums")
     return s
 
