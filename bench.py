@@ -1,0 +1,177 @@
+#!/usr/bin/env python3
+"""bench.py -- throughput of the ConvAE + gender-adversarial train step on MI355X.
+
+  python bench.py --gpus N --steps K --warmup W          (N = 1 default)
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+         --master-port P bench.py --gpus N --steps K --warmup W
+
+One "step" = SexAnonymizationTraining.fit_batch on one synthetic 16 kHz batch per rank (weak
+scaling): Fbank x2 + InputNormalization x2 + ConvAutoencoder fwd + L1 recon / NLL losses +
+backward + clip_grad_norm_(5.0) + Adam + Noam (+ SyncBN statistic and gradient all-reduce on
+N > 1).  Workload = BASELINE.json configs[1]: recon 0.1 + sex 0.9 adversarial, shape M of
+SURVEY.md 8(d): B utterances of 161 120 samples -> T = 1008 frames each.  Inputs are resident in
+HBM when the timed region starts.  Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
+MFMA_PEAK_TFLOPS = {"bf16": 2500.0, "f32": 157.3}
+N_SAMPLES = 161120               # -> T = 1 + N // 160 = 1008 frames (already a multiple of 36)
+BYTES_PER_FRAME = {"f32": 862400, "bf16": 431200}       # SURVEY.md 8(d) algorithmic step traffic
+
+
+def build_brain(device, dtype_name, batch):
+    import speech_anonymization_amd as pkg
+    from speech_anonymization_amd import brain as B, convae, losses
+    dt = torch.bfloat16 if dtype_name == "bf16" else torch.float32
+    torch.manual_seed(8886)
+    model = convae.ConvAutoencoder(dtype=dt)
+    hparams = dict(
+        model_type="convae", compute_features=pkg.Fbank(16000, 400, 80).to(device),
+        epoch_counter=B.EpochCounter(500),
+        loss_reconstruction=losses.L1Loss(), loss_sex_classification=losses.NLLLoss(),
+        loss_confusion=losses.ConfusionLoss(),
+        recon_loss_weight=0.1, sex_loss_weight=0.9, utility_loss_weight=0.0,
+        confusion_loss_weight=0.0, gradient_accumulation=1,
+        noam_annealing=B.NoamScheduler(1.0, 25000, 768))
+    hparams["epoch_counter"].current = 1
+    import functools
+    adam_kw = dict(lr=0.001, betas=(0.9, 0.98), eps=1e-9)
+    brain = B.SexAnonymizationTraining(
+        modules={"normalize": pkg.InputNormalization("global", update_until_epoch=4)},
+        opt_class=functools.partial(torch.optim.Adam, **adam_kw), hparams=hparams,
+        run_opts={"device": str(device), "max_grad_norm": 5.0})
+    brain.modules["ConvAE"] = model.to(device)
+    brain.on_fit_start()
+    brain.modules.train()
+    return brain
+
+
+def synthetic_batch(batch, rank, device):
+    """0.1*randn + 220 Hz / 1 kHz / 3.4 kHz sinusoids, clipped, seed 8886+rank."""
+    from speech_anonymization_amd.brain import Batch
+    g = torch.Generator(device="cpu").manual_seed(8886 + rank)
+    t = torch.arange(N_SAMPLES, dtype=torch.float64) / 16000.0
+    w = 0.1 * torch.randn(batch, N_SAMPLES, generator=g, dtype=torch.float64)
+    for f, a in ((220.0, 0.2), (1000.0, 0.1), (3400.0, 0.05)):
+        w += a * torch.sin(2 * torch.pi * f * t)[None, :]
+    # utterances differ (amplitude / spectral tilt) like real batches do
+    w *= torch.linspace(0.5, 1.5, batch, dtype=torch.float64)[:, None]
+    wav = w.clamp(-1, 1).float().to(device)
+    lens = torch.ones(batch, device=device)
+    gender = (torch.arange(batch) % 2).to(device)
+    return Batch(wav, lens, gender)
+
+
+def cpu_baseline(threads):
+    """the oracle (CPU restatement of the reference step, same ATen kernels) on a bounded sample."""
+    from oracle.train_step import OracleTrainer
+    from oracle.features import synthetic_wave
+    Bc, steps = 4, 2
+    tr = OracleTrainer(threads=threads)
+    wav = synthetic_wave(Bc, N_SAMPLES, seed=8886)
+    lens, gender = torch.ones(Bc), torch.arange(Bc) % 2
+    tr.fit_batch(wav, lens, gender)                       # warm-up
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        tr.fit_batch(wav, lens, gender)
+    dt = (time.perf_counter() - t0) / steps
+    return {"value": Bc * 1008 / dt, "unit": "frames/s", "cores": threads, "kind": "port",
+            "sample": f"oracle train step (torch CPU fp32), B={Bc} x T=1008 frames, 1 warm-up + {steps} timed steps"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=10, help="utterances per GPU (shape M: 10)")
+    ap.add_argument("--dtype", default=os.environ.get("SA_BENCH_DTYPE", "bf16"), choices=["bf16", "f32"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    from speech_anonymization_amd import distributed as sdist, ops
+    rank, local_rank, world = sdist.ddp_init_group()
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+    device = torch.device("cuda", local_rank)
+    torch.cuda.set_device(device)
+
+    brain = build_brain(device, args.dtype, args.batch)
+    batch = synthetic_batch(args.batch, rank, device)
+    T = 1 + N_SAMPLES // 160
+
+    def sync_all():
+        if world > 1:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        brain.step += 1
+        brain.fit_batch(batch)
+    sync_all()
+    ops.PROFILE.enable("conv_gemm(128,128,1,1)")          # dominant kernel: timed live with HIP events
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        brain.step += 1
+        loss = brain.fit_batch(batch)
+    sync_all()
+    elapsed = time.perf_counter() - t0
+    prof = ops.PROFILE.collect()
+    if world > 1:
+        tt = torch.tensor([elapsed], device=device, dtype=torch.float64)
+        torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
+        elapsed = float(tt)
+    frames = world * args.batch * T * args.steps
+    value = frames / elapsed
+
+    if rank == 0:
+        esz = 2 if args.dtype == "bf16" else 4
+        roof = None
+        if prof["launches"]:
+            avg_s = prof["ms"] * 1e-3 / prof["launches"]
+            nbytes, flops = prof["bytes"] / prof["launches"], prof["flops"] / prof["launches"]
+            t_hbm, t_mfma = nbytes / (HBM_PEAK_GBS * 1e9), flops / (MFMA_PEAK_TFLOPS[args.dtype] * 1e12)
+            if t_hbm >= t_mfma:
+                roof = {"bound": "hbm", "achieved": nbytes / avg_s / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s"}
+            else:
+                roof = {"bound": "mfma", "achieved": flops / avg_s / 1e12,
+                        "peak": MFMA_PEAK_TFLOPS[args.dtype], "unit": "TFLOP/s"}
+            roof["frac"] = roof["achieved"] / roof["peak"]
+            roof["traffic"] = None
+            roof["kernel"] = "sa_conv_gemm_kernel<%s,128,128,1,1>" % ("bf16" if esz == 2 else "float")
+            roof["avg_us"] = avg_s * 1e6
+            roof["hbm_gbs"] = nbytes / avg_s / 1e9
+            roof["tflops"] = flops / avg_s / 1e12
+        out = {
+            "metric": "audio frames/sec (node), ConvAE+gender-adv train step", "value": value,
+            "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+            "config": {"workload": "ConvAE recon0.1+sex0.9 adversarial train step (L1 recon + NLL), "
+                                   f"shape M: {args.batch} utt/GPU x 161120 samples (T=1008 frames), "
+                                   "Fbank x2 + norm + fwd + bwd + clip + Adam + Noam",
+                       "batch_per_gpu": args.batch, "frames_per_utt": T, "parallelism": f"dp{world}",
+                       "loss": float(loss)},
+            "step_hbm_roofline_frac": value * BYTES_PER_FRAME[args.dtype] / (world * HBM_PEAK_GBS * 1e9),
+            "roofline": roof,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(min(16, len(os.sched_getaffinity(0))))
+        print(json.dumps(out))
+    if world > 1:
+        torch.distributed.barrier()
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

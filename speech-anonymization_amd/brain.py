@@ -1,0 +1,316 @@
+"""Host-side training loop: a minimal ``Brain`` with speechbrain's hook order, and
+``SexAnonymizationTraining`` mirroring the reference's overrides one for one
+(speechbrain_convae_train.py:41-416: compute_forward :42-69, compute_objectives :71-193,
+fit_batch :195-259, evaluate_batch :271-276).  speechbrain is not a dependency: the loop, the
+Noam schedule, the epoch counter, check_gradients (non-finite guard + clip_grad_norm_) and the
+DDP initialisation are restated here.  All per-batch tensor work happens in libsa_hip.so.
+"""
+import enum
+import os
+import types
+
+import torch
+
+from . import distributed as sdist
+
+
+class Stage(enum.Enum):
+    TRAIN = 1
+    VALID = 2
+    TEST = 3
+
+
+class EpochCounter:
+    """speechbrain.utils.epoch_loop.EpochCounter"""
+
+    def __init__(self, limit):
+        self.current, self.limit = 0, int(limit)
+
+    def __iter__(self):
+        return self
+
+    def __next__(self):
+        if self.current < self.limit:
+            self.current += 1
+            return self.current
+        raise StopIteration
+
+
+class NoamScheduler:
+    """speechbrain.nnet.schedulers.NoamScheduler: lr = lr_initial * model_size^-0.5 *
+    min(n^-0.5, n * n_warmup^-1.5); pinned by the lr column of the reference's train_log.txt."""
+
+    def __init__(self, lr_initial, n_warmup_steps, model_size=None):
+        self.lr_initial, self.n_warmup_steps = lr_initial, n_warmup_steps
+        self.current_lr, self.n_steps = lr_initial, 0
+        self.normalize = n_warmup_steps ** 0.5 if model_size is None else model_size ** (-0.5)
+
+    def __call__(self, opt):
+        self.n_steps += 1
+        current_lr = opt.param_groups[0]["lr"]
+        lr = self.lr_initial * self.normalize * min(self.n_steps ** (-0.5),
+                                                    self.n_steps * self.n_warmup_steps ** (-1.5))
+        for g in opt.param_groups:
+            g["lr"] = lr
+        self.current_lr = current_lr
+        return current_lr, lr
+
+    def state_dict(self):
+        return {"losses": [], "n_steps": self.n_steps}
+
+    def load_state_dict(self, sd):
+        self.n_steps = sd["n_steps"]
+
+
+class Batch:
+    """what speechbrain's PaddedBatch gives the hooks: .sig = (wavs, rel. lengths), .gender,
+    .tokens_bos, .to(device) (speechbrain_convae_train.py:45-47,77-80,508-510)."""
+
+    def __init__(self, wavs, lens, gender, tokens_bos=None, ids=None):
+        self.sig = (wavs, lens)
+        self.gender = gender
+        self.tokens_bos = (tokens_bos if tokens_bos is not None
+                           else torch.ones(wavs.shape[0], 1, dtype=torch.long), lens)
+        self.id = ids
+
+    def to(self, device):
+        w, l = self.sig
+        tb, tl = self.tokens_bos
+        out = Batch.__new__(Batch)
+        out.sig = (w.to(device, non_blocking=True), l.to(device, non_blocking=True))
+        out.gender = self.gender.to(device, non_blocking=True)
+        out.tokens_bos = (tb.to(device, non_blocking=True), tl.to(device, non_blocking=True))
+        out.id = self.id
+        return out
+
+
+class Brain:
+    """The subset of speechbrain.core.Brain the reference relies on."""
+
+    def __init__(self, modules=None, opt_class=None, hparams=None, run_opts=None, checkpointer=None):
+        run_opts = dict(run_opts or {})
+        self.device = torch.device(run_opts.get("device", "cuda:0" if torch.cuda.is_available() else "cpu"))
+        self.max_grad_norm = float(run_opts.get("max_grad_norm", 5.0))
+        self.nonfinite_patience = int(run_opts.get("nonfinite_patience", 3))
+        self.distributed_launch = bool(run_opts.get("distributed_launch", sdist.is_distributed()))
+        self.modules = torch.nn.ModuleDict(modules or {})
+        self.opt_class = opt_class
+        self.hparams = types.SimpleNamespace(**(hparams or {}))
+        self.checkpointer = checkpointer
+        self.step, self.nonfinite_count, self.optimizer = 0, 0, None
+        self.avg_train_loss = 0.0
+
+    # ---- hooks to override
+    def compute_forward(self, batch, stage):
+        raise NotImplementedError
+
+    def compute_objectives(self, predictions, batch, stage):
+        raise NotImplementedError
+
+    def on_stage_start(self, stage, epoch=None):
+        pass
+
+    def on_stage_end(self, stage, stage_loss, epoch=None):
+        pass
+
+    def on_fit_start(self):
+        self.modules.to(self.device)
+        self.init_optimizers()
+
+    def init_optimizers(self):
+        if self.opt_class is not None and self.optimizer is None:
+            self.optimizer = self.opt_class(self.modules.parameters())
+
+    def check_gradients(self, loss):
+        """speechbrain semantics: count non-finite losses (raise after `nonfinite_patience`),
+        otherwise clip the global gradient norm to max_grad_norm."""
+        if not torch.isfinite(loss):
+            self.nonfinite_count += 1
+            if self.nonfinite_count > self.nonfinite_patience:
+                raise ValueError("Loss is not finite and patience is exhausted.")
+            return False
+        torch.nn.utils.clip_grad_norm_((p for p in self.modules.parameters()), self.max_grad_norm)
+        return True
+
+    def fit_batch(self, batch):
+        outputs = self.compute_forward(batch, Stage.TRAIN)
+        loss = self.compute_objectives(outputs, batch, Stage.TRAIN)
+        loss.backward()
+        if self.check_gradients(loss):
+            self.optimizer.step()
+        self.optimizer.zero_grad()
+        return loss.detach()
+
+    def evaluate_batch(self, batch, stage):
+        out = self.compute_forward(batch, stage=stage)
+        return self.compute_objectives(out, batch, stage=stage).detach()
+
+    def update_average(self, loss, avg_loss):
+        if torch.isfinite(loss):
+            avg_loss -= avg_loss / self.step
+            avg_loss += float(loss) / self.step
+        return avg_loss
+
+    def fit(self, epoch_counter, train_set, valid_set=None, progressbar=False, **_):
+        self.on_fit_start()
+        for epoch in epoch_counter:
+            self.on_stage_start(Stage.TRAIN, epoch)
+            self.modules.train()
+            self.nonfinite_count = 0
+            self.avg_train_loss = 0.0
+            self.step = 0
+            for batch in train_set:
+                self.step += 1
+                loss = self.fit_batch(batch)
+                self.avg_train_loss = self.update_average(loss, self.avg_train_loss)
+            self.on_stage_end(Stage.TRAIN, self.avg_train_loss, epoch)
+            if valid_set is not None:
+                self.on_stage_start(Stage.VALID, epoch)
+                self.modules.eval()
+                avg, n = 0.0, 0
+                with torch.no_grad():
+                    for batch in valid_set:
+                        n += 1
+                        avg += (float(self.evaluate_batch(batch, Stage.VALID)) - avg) / n
+                self.on_stage_end(Stage.VALID, avg, epoch)
+
+    def evaluate(self, test_set, **_):
+        self.on_stage_start(Stage.TEST, None)
+        self.modules.eval()
+        avg, n = 0.0, 0
+        with torch.no_grad():
+            for batch in test_set:
+                n += 1
+                avg += (float(self.evaluate_batch(batch, Stage.TEST)) - avg) / n
+        self.on_stage_end(Stage.TEST, avg, None)
+        return avg
+
+
+class SexAnonymizationTraining(Brain):
+    """The reference's Brain subclass for model_type convae / endtoend (ASR utility loss and the
+    external-classifier evaluation are out of scope of this path: SURVEY.md 8f)."""
+
+    def features(self, wavs, wav_lens):
+        feats = self.hparams.compute_features(wavs)
+        current_epoch = self.hparams.epoch_counter.current
+        # normalisation, top-dB clamp and the pad-to-36 (speechbrain_convae_train.py:62-63) are
+        # one fused pass
+        pad = 36 if self.hparams.model_type != "fcae" else None
+        return self.modules.normalize(feats, wav_lens, epoch=current_epoch, pad_multiple=pad)
+
+    def compute_forward(self, batch, stage):
+        batch = batch.to(self.device)
+        wavs, wav_lens = batch.sig
+        feats = self.features(wavs, wav_lens)
+        return self.modules.ConvAE(feats)
+
+    def compute_objectives(self, predictions, batch, stage):
+        reconstructed_speech, sex_logits = predictions
+        batch = batch.to(self.device)
+        sex_label = batch.gender
+        wavs, wav_lens = batch.sig
+        feats = self.features(wavs, wav_lens)          # the reference recomputes the targets (:82-87)
+        hp = self.hparams
+        utility_loss = 0.0
+        B = reconstructed_speech.shape[0]
+        recon_loss = hp.loss_reconstruction(reconstructed_speech.view(B, -1), feats.view(B, -1))
+        sex_loss = hp.loss_sex_classification(sex_logits, sex_label)
+        if hp.model_type == "endtoend":
+            if hp.recon_loss_weight == 0.0 and hp.utility_loss_weight == 0.0:
+                loss = hp.sex_loss_weight * sex_loss
+            else:
+                confusion_loss = hp.loss_confusion(sex_logits, None)
+                loss = (hp.recon_loss_weight * recon_loss - hp.sex_loss_weight * sex_loss
+                        + hp.utility_loss_weight * utility_loss
+                        - hp.confusion_loss_weight * confusion_loss)
+        else:
+            loss = (hp.recon_loss_weight * recon_loss + hp.sex_loss_weight * sex_loss
+                    + hp.utility_loss_weight * utility_loss)
+        self.last_losses = dict(recon=recon_loss.detach(), sex=sex_loss.detach())
+        if stage != Stage.TRAIN:
+            pred = sex_logits.argmax(dim=1)
+            self.eval_correct += int((pred == sex_label).sum())
+            self.eval_total += int(sex_label.numel())
+        return loss
+
+    def apply_epoch_schedule(self):
+        """HEAD's epoch-parity schedule (speechbrain_convae_train.py:212-235), enabled with
+        hparams.epoch_parity_schedule; the historical runs (results/*/hyperparams.yaml) trained
+        every parameter with fixed weights, which is the default here."""
+        hp = self.hparams
+        if not getattr(hp, "epoch_parity_schedule", False):
+            return
+        joint = hp.epoch_counter.current % 2 == 0
+        if joint:
+            hp.recon_loss_weight, hp.sex_loss_weight = 0.0, 0.8
+            hp.utility_loss_weight, hp.confusion_loss_weight = 0.2, 0.0
+        else:
+            hp.recon_loss_weight, hp.sex_loss_weight, hp.utility_loss_weight = 0.0, 0.5, 0.0
+        for name, param in self.modules.ConvAE.named_parameters():
+            param.requires_grad = ("sex_classifier" not in name) if joint else ("sex_classifier" in name)
+
+    def fit_batch(self, batch):
+        self.apply_epoch_schedule()
+        predictions = self.compute_forward(batch, Stage.TRAIN)
+        loss = self.compute_objectives(predictions, batch, Stage.TRAIN)
+        (loss / self.hparams.gradient_accumulation).backward()
+        if self.step % self.hparams.gradient_accumulation == 0:
+            self.check_gradients(loss)          # return value ignored, like the reference (:249-251)
+            self.optimizer.step()
+            self.optimizer.zero_grad()
+            self.hparams.noam_annealing(self.optimizer)
+        return loss.detach()
+
+    def evaluate_batch(self, batch, stage):
+        with torch.no_grad():
+            predictions = self.compute_forward(batch, stage=stage)
+            loss = self.compute_objectives(predictions, batch, stage=stage)
+        return loss.detach()
+
+    def on_stage_start(self, stage, epoch=None):
+        if stage != Stage.TRAIN:
+            self.eval_correct, self.eval_total = 0, 0
+
+    def on_stage_end(self, stage, stage_loss, epoch=None):
+        stats = {"loss": stage_loss}
+        if stage == Stage.TRAIN:
+            self.train_stats = stats
+            return
+        stats["ACC"] = self.eval_correct / max(1, self.eval_total)
+        self.valid_stats = stats
+        logger = getattr(self.hparams, "train_logger", None)
+        if stage == Stage.VALID and sdist.if_main_process() and logger is not None:
+            na = self.hparams.noam_annealing
+            logger.log_stats(stats_meta={"epoch": epoch, "lr": na.current_lr, "steps": na.n_steps,
+                                         "optimizer": self.optimizer.__class__.__name__},
+                             train_stats=self.train_stats, valid_stats=stats)
+        if stage == Stage.VALID and sdist.if_main_process() and self.checkpointer is not None:
+            self.checkpointer.save(self, epoch, stats)
+
+
+class FileTrainLogger:
+    """speechbrain.utils.train_logger.FileTrainLogger line format
+    (results/*/train_log.txt: "epoch: 1, lr: 2.60e-05, steps: 2854, optimizer: Adam - train loss: ...")."""
+
+    def __init__(self, save_file):
+        self.save_file = save_file
+
+    @staticmethod
+    def _fmt(d):
+        out = []
+        for k, v in d.items():
+            if isinstance(v, float) and 1.0 < abs(v) < 100.0:
+                v = f"{v:.2f}"
+            elif isinstance(v, float):
+                v = f"{v:.2e}"
+            out.append(f"{k}: {v}")
+        return ", ".join(out)
+
+    def log_stats(self, stats_meta, train_stats=None, valid_stats=None, test_stats=None):
+        s = self._fmt(stats_meta)
+        for name, st in (("train", train_stats), ("valid", valid_stats), ("test", test_stats)):
+            if st is not None:
+                s += " - " + self._fmt({f"{name} {k}": v for k, v in st.items()})
+        os.makedirs(os.path.dirname(os.path.abspath(self.save_file)), exist_ok=True)
+        with open(self.save_file, "a") as f:
+            f.write(s + "\n")

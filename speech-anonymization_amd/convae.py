@@ -16,6 +16,7 @@ Their ``forward`` is never called: one ``torch.autograd.Function`` runs the fuse
 import torch
 import torch.nn as nn
 
+from . import distributed as sdist
 from . import ops
 from ._lib import SaHipError
 
@@ -88,6 +89,11 @@ class ConvAutoencoder(nn.Module):
     def forward(self, feats):
         names, params = zip(*self.named_parameters())
         return _ConvAEFn.apply(self, names, feats, *params)
+
+    def _side_stream(self, device):
+        if getattr(self, "_side", None) is None and device.type == "cuda":
+            self._side = torch.cuda.Stream(device=device)
+        return getattr(self, "_side", None)
 
     # ---- SyncBatchNorm support: statistics sums are all-reduced across data-parallel ranks
     # (what speechbrain's Brain applies under DDP); identity on one process.
@@ -223,7 +229,11 @@ class _ConvAEFn(torch.autograd.Function):
         dev = y0.device
         G = {k: None for k in names}
         need = {k: p.requires_grad for k, p in P.items()}
-        newg = lambda k: torch.empty_like(P[k])
+        buckets = sdist.StageBuckets(list(P.items()), dev, model._side_stream(dev))
+        newg = buckets.view
+
+        def setg(key, val):
+            G[key] = newg(key).copy_(val.reshape(P[key].shape))
         pw = lambda k, kind: ops.pack_weights(P[k], kind, dt)
 
         def bias_from(stats, key, C):
@@ -279,7 +289,7 @@ class _ConvAEFn(torch.autograd.Function):
             d_logp = torch.zeros(B, 2, device=dev)
         g_rec = d_recon.reshape(B, Ltot).contiguous().float()
         if need["decoder.8.bias"]:
-            G["decoder.8.bias"] = ops.sum_partials(g_rec, 1, n=80).sum().float().view(1)
+            setg("decoder.8.bias", ops.sum_partials(g_rec, 1, n=80).sum())
         if need["decoder.8.weight"]:
             G["decoder.8.weight"] = ops.wgrad1C(g_rec, y8, newg("decoder.8.weight"), flip=True,
                                                 s1=n8[2], t1=n8[3], swish=True)
@@ -301,24 +311,25 @@ class _ConvAEFn(torch.autograd.Function):
         da4_dec = ops.conv_gemm(g, pw("decoder.0.weight", "conv_dgrad"), None, 128, 128, 1, 1,
                                 ops.taps_conv_dgrad_s1(K5, 1, 2), L4)
 
+        buckets.reduce_stage("decoder")
         # ======================= sex classifier =======================
         c = "sex_classifier.classify."
         dLG = ops.log_softmax_bwd(d_logp.contiguous().float(), S["logp"])
         H1, H2 = S["H1"], S["H2"]
         G[c + "6.weight"] = ops.dense_wgrad(dLG, H2, newg(c + "6.weight"), ps=f2[2], pt=f2[3])
-        G[c + "6.bias"] = ops.colsums(dLG)[:, 0].float()
+        setg(c + "6.bias", ops.colsums(dLG)[:, 0])
         dN2 = ops.dense(dLG, P[c + "6.weight"], None, 64, 2, transpose_w=True)
         l2 = ops.colsums(dN2, H2, f2[0], f2[1]); g2s = l2.clone(); w = model._bn_allreduce(g2s)
-        G[c + "5.weight"], G[c + "5.bias"] = l2[:, 1].float(), l2[:, 0].float()
+        setg(c + "5.weight", l2[:, 1]); setg(c + "5.bias", l2[:, 0])
         dH2 = ops.bn2d_bwd(dN2, H2, g2s, B * w, P[c + "5.weight"], f2[0], f2[1], True)
         G[c + "3.weight"] = ops.dense_wgrad(dH2, H1, newg(c + "3.weight"), ps=f1[2], pt=f1[3])
-        G[c + "3.bias"] = ops.colsums(dH2)[:, 0].float()
+        setg(c + "3.bias", ops.colsums(dH2)[:, 0])
         dN1 = ops.dense(dH2, P[c + "3.weight"], None, 128, 64, transpose_w=True)
         l1 = ops.colsums(dN1, H1, f1[0], f1[1]); g1s = l1.clone(); w = model._bn_allreduce(g1s)
-        G[c + "2.weight"], G[c + "2.bias"] = l1[:, 1].float(), l1[:, 0].float()
+        setg(c + "2.weight", l1[:, 1]); setg(c + "2.bias", l1[:, 0])
         dH1 = ops.bn2d_bwd(dN1, H1, g1s, B * w, P[c + "2.weight"], f1[0], f1[1], True)
         G[c + "0.weight"] = ops.dense_wgrad(dH1, S["pooled"], newg(c + "0.weight"))
-        G[c + "0.bias"] = ops.colsums(dH1)[:, 0].float()
+        setg(c + "0.bias", ops.colsums(dH1)[:, 0])
         dP = ops.dense(dH1, P[c + "0.weight"], None, 256, 128, transpose_w=True)
         t = "sex_classifier.tdnn."
         g = ops.pool_bwd(r2, bn2[2], bn2[3], dP, S["pmean"], S["psd"])
@@ -337,6 +348,7 @@ class _ConvAEFn(torch.autograd.Function):
                           ops.taps_conv_dgrad_s1(5, 1, 0), L4)
         da4_cls = bn_block(g, y4, bn_n, L4, "sex_classifier.norm", None, xp=(n4[2], n4[3]))   # includes GRL
 
+        buckets.reduce_stage("sex_classifier")
         # ======================= encoder =======================
         g = in_block(da4_dec, y4, n4, 128, L4, "encoder.12", "encoder.11.bias", g2=da4_cls)  # d y4
         conv_wgrad("encoder.11.weight", y3, g, 128, 128, 1, L4, K5, 1, 2, s1=n3[2], t1=n3[3], swish=True)
@@ -359,6 +371,8 @@ class _ConvAEFn(torch.autograd.Function):
         d_feats = None
         if ctx.need_input_grad:
             d_feats = ops.convCto1(g, P["encoder.0.weight"], None, flip=True).view(B, T, 80)
+        buckets.reduce_stage("encoder")
+        buckets.join()
         ctx.S = None
         grads = tuple(G[k] if need[k] else None for k in names)
         return (None, None, d_feats) + grads

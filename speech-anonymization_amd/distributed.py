@@ -1,0 +1,113 @@
+"""Data-parallel plumbing: one process per GPU, torch.distributed over RCCL ("nccl" backend on
+ROCm) on xGMI.  Replaces what speechbrain does for the reference at
+speechbrain_convae_train.py:524 (ddp_init_group), :534 (run_on_main), :314 (if_main_process) and
+the DistributedDataParallel / SyncBatchNorm wrap inside Brain.
+
+The path shards by utterance: each rank runs the whole step on its own B utterances; the only
+exchanges are (1) the tiny BatchNorm statistic sums of the classifier (SyncBatchNorm semantics,
+convae.ConvAutoencoder._bn_allreduce) and (2) the gradient average.  Gradients are written by
+the backward kernels straight into three flat fp32 stage buckets (decoder 0.62 MB, classifier
+0.89 MB, encoder 0.62 MB); each bucket is all-reduced on a SIDE stream as soon as its stage is
+complete, so the collective (latency-bound at this size) overlaps the rest of backward, and the
+main stream joins the side stream once, before the optimizer touches the gradients.
+"""
+import os
+
+import torch
+import torch.distributed as dist
+
+
+def is_distributed():
+    return int(os.environ.get("WORLD_SIZE", "1")) > 1
+
+
+def world_size():
+    return dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+
+
+def rank():
+    return dist.get_rank() if dist.is_available() and dist.is_initialized() else 0
+
+
+def if_main_process():
+    return rank() == 0
+
+
+def run_on_main(func, args=None, kwargs=None):
+    if if_main_process():
+        func(*(args or ()), **(kwargs or {}))
+    if world_size() > 1:
+        dist.barrier()
+
+
+def ddp_init_group(run_opts=None):
+    """init_process_group from the torchrun environment (RANK / LOCAL_RANK / WORLD_SIZE /
+    MASTER_ADDR / MASTER_PORT).  backend: run_opts["distributed_backend"] or nccl on GPU, gloo on
+    CPU.  Returns (rank, local_rank, world_size)."""
+    run_opts = run_opts or {}
+    ws = int(os.environ.get("WORLD_SIZE", "1"))
+    rk = int(os.environ.get("RANK", "0"))
+    lr = int(os.environ.get("LOCAL_RANK", "0"))
+    if ws > 1 and not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29500")
+        backend = run_opts.get("distributed_backend") or ("nccl" if torch.cuda.is_available() else "gloo")
+        if backend == "nccl":
+            torch.cuda.set_device(lr)
+            dist.init_process_group(backend, rank=rk, world_size=ws,
+                                    device_id=torch.device("cuda", lr))
+        else:
+            dist.init_process_group(backend, rank=rk, world_size=ws)
+    return rk, lr, ws
+
+
+def shard_batch(n_items, rank_, world):
+    """contiguous utterance shard [lo, hi) of rank `rank_` (weak scaling: the caller normally
+    builds B utterances per rank; this is for sharding a fixed global list)."""
+    per = -(-n_items // world)
+    lo = min(n_items, rank_ * per)
+    return lo, min(n_items, lo + per)
+
+
+class StageBuckets:
+    """Flat fp32 gradient buckets, one per backward stage, with views handed to the kernels."""
+
+    STAGES = ("decoder", "sex_classifier", "encoder")
+
+    def __init__(self, named_params, device, side_stream=None):
+        self.views, self.flat = {}, {}
+        for st in self.STAGES:
+            items = [(k, p) for k, p in named_params if k.startswith(st)]
+            n = sum(p.numel() for _, p in items)
+            flat = torch.empty(n, dtype=torch.float32, device=device)
+            off = 0
+            for k, p in items:
+                self.views[k] = flat[off:off + p.numel()].view_as(p)
+                off += p.numel()
+            self.flat[st] = flat
+        self.side = side_stream
+        self.pending = False
+
+    def view(self, key):
+        return self.views[key]
+
+    def reduce_stage(self, stage):
+        """average bucket `stage` across ranks, asynchronously on the side stream."""
+        w = world_size()
+        if w == 1:
+            return
+        flat = self.flat[stage]
+        if self.side is None:                      # CPU / gloo (tests)
+            dist.all_reduce(flat)
+            flat.div_(w)
+            return
+        self.side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(self.side):
+            dist.all_reduce(flat)
+            flat.div_(w)
+        self.pending = True
+
+    def join(self):
+        if self.pending:
+            torch.cuda.current_stream().wait_stream(self.side)
+            self.pending = False

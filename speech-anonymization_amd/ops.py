@@ -34,6 +34,42 @@ def _f(t):
     return L.ptr(t)
 
 
+class _Profile:
+    """HIP-event timing of ONE kernel family during bench.py's timed region (the events are
+    recorded on the stream the kernel is launched on = torch's current stream)."""
+
+    def __init__(self):
+        self.key, self.ev, self.bytes, self.flops = None, [], 0, 0
+
+    def enable(self, key):
+        self.key, self.ev, self.bytes, self.flops = key, [], 0, 0
+
+    def start(self, key):
+        if key != self.key:
+            return None
+        e = torch.cuda.Event(enable_timing=True)
+        e.record()
+        return e
+
+    def stop(self, e0, nbytes, flops):
+        e1 = torch.cuda.Event(enable_timing=True)
+        e1.record()
+        self.ev.append((e0, e1))
+        self.bytes += nbytes
+        self.flops += flops
+
+    def collect(self):
+        torch.cuda.synchronize()
+        ms = sum(a.elapsed_time(b) for a, b in self.ev)
+        out = {"kernel": self.key, "launches": len(self.ev), "ms": ms, "bytes": self.bytes,
+               "flops": self.flops}
+        self.key, self.ev = None, []
+        return out
+
+
+PROFILE = _Profile()
+
+
 def pack_weights(w, kind, dtype):
     """w: fp32 parameter in PyTorch layout.  kind: conv_fwd | conv_dgrad | convT_fwd |
     convT_dgrad.  Returns the fragment-major operand image (flat tensor of `dtype`)."""
@@ -71,8 +107,14 @@ def conv_gemm(x, wp, bias, cin, cout, sa, u, phases, Lout, s1=None, t1=None, s2=
     a.swish, a.relu, a.stats = int(swish), int(relu), _f(stats)
     a.B, a.Lin, a.Lout = B, Lin, Lout
     a.taps = L.make_taps(phases)
+    e0 = PROFILE.start(f"conv_gemm({cin},{cout},{sa},{u})") if PROFILE.key else None
     L.check(lib.sa_conv_gemm(L.dt_code(x.dtype), cin, cout, sa, u, C.byref(a), L.stream()),
             f"sa_conv_gemm({cin},{cout},{sa},{u})")
+    if e0 is not None:
+        ntap = sum(len(p) for p in phases)
+        esz = x.element_size()
+        PROFILE.stop(e0, (x.numel() + y.numel()) * esz + ntap * cin * cout * esz,
+                     2 * B * (-(-Lout // u)) * ntap * cin * cout)
     return (y, stats) if want_stats else y
 
 

@@ -1,0 +1,39 @@
+"""Whole-step parity on the GPU (Brain hooks -> HIP library) against the oracle's step."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def test_train_step_fp32_matches_oracle():
+    from tests import smoke_step
+    smoke_step.run(torch.float32)
+
+
+def test_train_step_bf16_runs_and_tracks_oracle():
+    from tests import smoke_step
+    smoke_step.run(torch.bfloat16)
+
+
+def test_frozen_classifier_and_recon_only():
+    """the reference's requires_grad toggling by name (speechbrain_convae_train.py:219-235) and
+    config 1 (recon 1.0 only, MSE): frozen parameters get no gradient, the rest still match."""
+    from oracle.convae import numpy_params
+    from tests import smoke_step
+    from speech_anonymization_amd.brain import Batch, Stage
+    dev = torch.device("cuda:0")
+    br = smoke_step.build(torch.float32, dev, numpy_params(8886))
+    br.hparams.recon_loss_weight, br.hparams.sex_loss_weight = 1.0, 0.0
+    for name, p in br.modules["ConvAE"].named_parameters():
+        p.requires_grad = "sex_classifier" not in name
+    wav = smoke_step.make_wave(3, 11360)
+    batch = Batch(wav, torch.ones(3), torch.arange(3) % 2)
+    out = br.compute_forward(batch, Stage.TRAIN)
+    loss = br.compute_objectives(out, batch, Stage.TRAIN)
+    loss.backward()
+    torch.cuda.synchronize()
+    for name, p in br.modules["ConvAE"].named_parameters():
+        if "sex_classifier" in name:
+            assert p.grad is None, name
+        else:
+            assert p.grad is not None and torch.isfinite(p.grad).all(), name
