@@ -25,6 +25,7 @@ extern "C" {
 
 #define SA_F32 0
 #define SA_BF16 1
+#define SA_BF16X3 2   /* fp32 storage, split-bf16 operands, 3 bf16 MFMAs per k-step */
 #define SA_MAX_TAPS 5
 
 /* ---- implicit-GEMM convolution (sa_conv_gemm.hip) -------------------------------------
@@ -53,8 +54,8 @@ typedef struct SaConvArgs {
   int swish;
   int relu;
   float* stats;
-  int B, Lin, Lout, ntiles;  /* ntiles, rowmin, nrows are filled in by the library */
-  int rowmin, nrows;
+  int B, Lin, Lout, ntiles;  /* ntiles, rowmin, nrows, wlo_off are filled in by the library */
+  int rowmin, nrows, wlo_off;
   SaTaps taps;
 } SaConvArgs;
 

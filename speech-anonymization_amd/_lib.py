@@ -11,7 +11,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libsa_hip.so")
 
-F32, BF16 = 0, 1
+F32, BF16, BF16X3 = 0, 1, 2
 MAX_TAPS = 5
 
 c_fp = C.POINTER(C.c_float)
@@ -28,7 +28,7 @@ class SaConvArgs(C.Structure):
                 ("s1", vp), ("t1", vp), ("s2", vp), ("t2", vp),
                 ("swish", C.c_int), ("relu", C.c_int), ("stats", vp),
                 ("B", C.c_int), ("Lin", C.c_int), ("Lout", C.c_int), ("ntiles", C.c_int),
-                ("rowmin", C.c_int), ("nrows", C.c_int), ("taps", SaTaps)]
+                ("rowmin", C.c_int), ("nrows", C.c_int), ("wlo_off", C.c_int), ("taps", SaTaps)]
 
 
 class SaWgradArgs(C.Structure):

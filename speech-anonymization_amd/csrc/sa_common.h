@@ -99,3 +99,42 @@ __device__ static inline float sa_wave_max(float v) {
 
 // ABI structs (SaTaps, SaConvArgs, SaWgradArgs, SaEwArgs) live in include/sa_hip.h
 static inline int sa_div_up(int a, int b) { return (a + b - 1) / b; }
+
+// ---- precision policies of the MFMA kernels -------------------------------------------
+//   SA_F32    : fp32 storage, fp32 LDS operands, v_mfma_f32_32x32x2_f32 (exact fp32)
+//   SA_BF16   : bf16 storage, bf16 LDS operands, one v_mfma_f32_32x32x16_bf16 per k-step
+//   SA_BF16X3 : fp32 storage; each operand is split on the fly into hi = bf16(v) and
+//               lo = bf16(v - hi) (two LDS planes / two weight images) and every k-step issues
+//               hi*hi + lo*hi + hi*lo on the bf16 MFMA: ~16 mantissa bits per operand at 3/16 of
+//               the fp32-MFMA cost.  This is the mode that meets the 1e-4 parity bar.
+struct bf16x3_t {};
+
+template <typename T> struct Pol;
+template <> struct Pol<float> {
+  typedef float store_t; typedef float lds_t; typedef float Frag;
+  static constexpr int NPL = 1, VEC = 4, KS = 2, PAD = 1;
+};
+template <> struct Pol<bf16_t> {
+  typedef bf16_t store_t; typedef bf16_t lds_t; typedef bf16x8 Frag;
+  static constexpr int NPL = 1, VEC = 8, KS = 16, PAD = 8;
+};
+template <> struct Pol<bf16x3_t> {
+  typedef float store_t; typedef bf16_t lds_t; typedef bf16x8 Frag;
+  static constexpr int NPL = 2, VEC = 4, KS = 16, PAD = 8;
+};
+
+__device__ static inline uint2 sa_pack_bf16x4(const float* f) {
+  return make_uint2(sa_pack_bf16x2(f[0], f[1]), sa_pack_bf16x2(f[2], f[3]));
+}
+// split 4 floats into hi / lo bf16 quadruples
+__device__ static inline void sa_split4(const float* f, uint2& hi, uint2& lo) {
+  float h[4], l[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const bf16_t hb = (bf16_t)f[j];
+    h[j] = (float)hb;
+    l[j] = f[j] - h[j];
+  }
+  hi = sa_pack_bf16x4(h);
+  lo = sa_pack_bf16x4(l);
+}

@@ -20,9 +20,11 @@
 
 template <typename T, int CIN, int COUT, int SA, int U>
 struct ConvCfg {
-  typedef Tr<T> tr;
-  static constexpr int VEC = tr::VEC;
-  static constexpr int KS = tr::KS;
+  typedef Pol<T> P;
+  typedef typename P::store_t S;
+  typedef typename P::lds_t LT;
+  static constexpr int VEC = P::VEC;                // storage elements per 16-byte chunk
+  static constexpr int KS = P::KS;
   static constexpr int KSTEPS = CIN / KS;
   static constexpr int NT = COUT / 32;
   static constexpr int VT = NT * U;                 // virtual n-tiles (phase, n-tile)
@@ -31,38 +33,37 @@ struct ConvCfg {
   static constexpr int WM = 4 / WN;                 // waves along M
   static constexpr int VPW = VT / WN;               // virtual n-tiles per wave
   static constexpr int MT = BMB / (32 * WM);        // 32-row m-tiles per wave
-  static constexpr int APITCH = CIN + (sizeof(T) == 2 ? 8 : 1);
-  static constexpr int OPITCH = COUT + (sizeof(T) == 2 ? 8 : 4);
+  static constexpr int APITCH = CIN + P::PAD;       // LDS operand pitch (lds_t elements)
+  static constexpr int OPITCH = COUT + (sizeof(S) == 2 ? 8 : 4);
   static constexpr int CHI = CIN / VEC;             // 16-byte chunks per input row
   static constexpr int RPPI = 256 / CHI;
-  static constexpr int CHO = COUT / VEC;
+  static constexpr int OVEC = 16 / sizeof(S);
+  static constexpr int CHO = COUT / OVEC;
   static constexpr int RPPO = 256 / CHO;
   static_assert(MT >= 1 && VT % WN == 0, "tile shape");
-  static size_t lds_bytes(int nrows) {
-    size_t a = (size_t)nrows * APITCH * sizeof(T);
-    size_t o = (size_t)128 * OPITCH * sizeof(T);
-    size_t m = a > o ? a : o;
-    m = (m + 15) & ~(size_t)15;
-    return m + (size_t)RPPO * COUT * 2 * sizeof(float);
-  }
-  static size_t red_off(int nrows) {
-    size_t a = (size_t)nrows * APITCH * sizeof(T);
-    size_t o = (size_t)128 * OPITCH * sizeof(T);
+  static size_t tile_bytes(int nrows) {
+    size_t a = (size_t)P::NPL * nrows * APITCH * sizeof(LT);
+    size_t o = (size_t)128 * OPITCH * sizeof(S);
     size_t m = a > o ? a : o;
     return (m + 15) & ~(size_t)15;
   }
+  static size_t lds_bytes(int nrows) { return tile_bytes(nrows) + (size_t)RPPO * COUT * 2 * sizeof(float); }
 };
 
 template <typename T, int CIN, int COUT, int SA, int U>
 __global__ __launch_bounds__(256) void sa_conv_gemm_kernel(SaConvArgs a, int red_off) {
   typedef ConvCfg<T, CIN, COUT, SA, U> C;
-  typedef Tr<T> tr;
-  typedef typename tr::Frag Frag;
-  constexpr int VEC = C::VEC;
+  typedef Pol<T> P;
+  typedef typename P::store_t S;
+  typedef typename P::lds_t LT;
+  typedef typename P::Frag Frag;
+  typedef Tr<S> tr;
+  constexpr int VEC = C::VEC, OVEC = C::OVEC;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  T* As = reinterpret_cast<T*>(smem);
-  T* Os = reinterpret_cast<T*>(smem);                       // overlays As after the main loop
+  LT* As = reinterpret_cast<LT*>(smem);
+  S* Os = reinterpret_cast<S*>(smem);                       // overlays As after the main loop
   float* red = reinterpret_cast<float*>(smem + red_off);
+  const int plane = a.nrows * C::APITCH;                    // lo plane offset (split mode)
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int tile = blockIdx.x, b = blockIdx.y;
@@ -80,16 +81,16 @@ __global__ __launch_bounds__(256) void sa_conv_gemm_kernel(SaConvArgs a, int red
       t2[j] = a.t2 ? a.t2[c * VEC + j] : 0.0f;
     }
     const bool has1 = a.s1 != nullptr, has2 = a.s2 != nullptr, sw = a.swish != 0;
-    const T* xb = reinterpret_cast<const T*>(a.x) + (size_t)b * a.Lin * CIN + c * VEC;
+    const S* xb = reinterpret_cast<const S*>(a.x) + (size_t)b * a.Lin * CIN + c * VEC;
     const int gbase = m0 * SA + a.rowmin;
     for (int r = r0; r < a.nrows; r += C::RPPI) {
       const int g = gbase + r;
-      uint4 u = make_uint4(0, 0, 0, 0);
+      float f[VEC];
+#pragma unroll
+      for (int j = 0; j < VEC; ++j) f[j] = 0.0f;
       if (g >= 0 && g < a.Lin) {
-        u = *reinterpret_cast<const uint4*>(xb + (size_t)g * CIN);
+        tr::unpack(*reinterpret_cast<const uint4*>(xb + (size_t)g * CIN), f);
         if (has1 || has2 || sw) {
-          float f[VEC];
-          tr::unpack(u, f);
 #pragma unroll
           for (int j = 0; j < VEC; ++j) {
             float v = f[j];
@@ -98,16 +99,19 @@ __global__ __launch_bounds__(256) void sa_conv_gemm_kernel(SaConvArgs a, int red
             if (has2) v = fmaf(v, s2[j], t2[j]);
             f[j] = v;
           }
-          u = tr::pack(f);
         }
       }
-      T* dst = As + (size_t)r * C::APITCH + c * VEC;
-      if constexpr (sizeof(T) == 2) {
-        *reinterpret_cast<uint4*>(dst) = u;
+      LT* dst = As + (size_t)r * C::APITCH + c * VEC;
+      if constexpr (P::NPL == 2) {
+        uint2 hi, lo;
+        sa_split4(f, hi, lo);
+        *reinterpret_cast<uint2*>(dst) = hi;
+        *reinterpret_cast<uint2*>(dst + plane) = lo;
+      } else if constexpr (sizeof(LT) == 2) {
+        *reinterpret_cast<uint4*>(dst) = tr::pack(f);
       } else {
         float* d = reinterpret_cast<float*>(dst);
-        d[0] = __uint_as_float(u.x); d[1] = __uint_as_float(u.y);
-        d[2] = __uint_as_float(u.z); d[3] = __uint_as_float(u.w);
+        d[0] = f[0]; d[1] = f[1]; d[2] = f[2]; d[3] = f[3];
       }
     }
   }
@@ -132,16 +136,29 @@ __global__ __launch_bounds__(256) void sa_conv_gemm_kernel(SaConvArgs a, int red
     for (int ti = 0; ti < ntaps; ++ti) {
       const int off = a.taps.off[ph][ti] - a.rowmin;
       const Frag* wt = wp + ((size_t)a.taps.widx[ph][ti] * C::KSTEPS * C::NT + nt) * 64 + lane;
-      const T* arow = As + (size_t)((wm * C::MT * 32 + (lane & 31)) * SA + off) * C::APITCH
-                      + (lane >> 5) * (C::KS / 2);
+      const LT* arow = As + (size_t)((wm * C::MT * 32 + (lane & 31)) * SA + off) * C::APITCH
+                       + (lane >> 5) * (C::KS / 2);
 #pragma unroll 4
       for (int ks = 0; ks < C::KSTEPS; ++ks) {
         const Frag bf = wt[(size_t)ks * C::NT * 64];
+        if constexpr (P::NPL == 2) {
+          const Frag bl = wt[(size_t)a.wlo_off + (size_t)ks * C::NT * 64];
 #pragma unroll
-        for (int mt = 0; mt < C::MT; ++mt) {
-          const Frag af = *reinterpret_cast<const Frag*>(arow + (size_t)mt * 32 * SA * C::APITCH
-                                                         + ks * C::KS);
-          acc[v][mt] = tr::mfma(af, bf, acc[v][mt]);
+          for (int mt = 0; mt < C::MT; ++mt) {
+            const LT* ap = arow + (size_t)mt * 32 * SA * C::APITCH + ks * C::KS;
+            const Frag ah = *reinterpret_cast<const Frag*>(ap);
+            const Frag al = *reinterpret_cast<const Frag*>(ap + plane);
+            acc[v][mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bf, acc[v][mt], 0, 0, 0);
+            acc[v][mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc[v][mt], 0, 0, 0);
+            acc[v][mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bf, acc[v][mt], 0, 0, 0);
+          }
+        } else {
+#pragma unroll
+          for (int mt = 0; mt < C::MT; ++mt) {
+            const Frag af = *reinterpret_cast<const Frag*>(arow + (size_t)mt * 32 * SA * C::APITCH
+                                                           + ks * C::KS);
+            acc[v][mt] = Tr<LT>::mfma(af, bf, acc[v][mt]);
+          }
         }
       }
     }
@@ -169,29 +186,29 @@ __global__ __launch_bounds__(256) void sa_conv_gemm_kernel(SaConvArgs a, int red
   __syncthreads();
   {
     const int c = tid % C::CHO, r0 = tid / C::CHO;
-    float ssum[VEC], ssq[VEC];
+    float ssum[OVEC], ssq[OVEC];
 #pragma unroll
-    for (int j = 0; j < VEC; ++j) { ssum[j] = 0.0f; ssq[j] = 0.0f; }
-    T* yb = reinterpret_cast<T*>(a.y) + (size_t)b * a.Lout * COUT + c * VEC;
+    for (int j = 0; j < OVEC; ++j) { ssum[j] = 0.0f; ssq[j] = 0.0f; }
+    S* yb = reinterpret_cast<S*>(a.y) + (size_t)b * a.Lout * COUT + c * OVEC;
     const int o0 = m0 * U;
     for (int r = r0; r < 128; r += C::RPPO) {
       const int o = o0 + r;
       if (o < a.Lout) {
-        const uint4 u = *reinterpret_cast<const uint4*>(Os + (size_t)r * C::OPITCH + c * VEC);
+        const uint4 u = *reinterpret_cast<const uint4*>(Os + (size_t)r * C::OPITCH + c * OVEC);
         *reinterpret_cast<uint4*>(yb + (size_t)o * COUT) = u;
         if (a.stats) {
-          float f[VEC];
+          float f[OVEC];
           tr::unpack(u, f);
 #pragma unroll
-          for (int j = 0; j < VEC; ++j) { ssum[j] += f[j]; ssq[j] = fmaf(f[j], f[j], ssq[j]); }
+          for (int j = 0; j < OVEC; ++j) { ssum[j] += f[j]; ssq[j] = fmaf(f[j], f[j], ssq[j]); }
         }
       }
     }
     if (a.stats) {
 #pragma unroll
-      for (int j = 0; j < VEC; ++j) {
-        red[((size_t)r0 * COUT + c * VEC + j) * 2 + 0] = ssum[j];
-        red[((size_t)r0 * COUT + c * VEC + j) * 2 + 1] = ssq[j];
+      for (int j = 0; j < OVEC; ++j) {
+        red[((size_t)r0 * COUT + c * OVEC + j) * 2 + 0] = ssum[j];
+        red[((size_t)r0 * COUT + c * OVEC + j) * 2 + 1] = ssq[j];
       }
     }
   }
@@ -222,8 +239,12 @@ static int launch_cfg(const SaConvArgs& a, hipStream_t st) {
       omax = a.taps.off[ph][t] > omax ? a.taps.off[ph][t] : omax;
     }
   if (omin > omax) return -22;
+  int wmax = 0;
+  for (int ph = 0; ph < U; ++ph)
+    for (int t = 0; t < a.taps.ntaps[ph]; ++t) wmax = a.taps.widx[ph][t] > wmax ? a.taps.widx[ph][t] : wmax;
   args.rowmin = omin;
   args.nrows = (C::BMB - 1) * SA + (omax - omin) + 1;
+  args.wlo_off = (wmax + 1) * C::KSTEPS * C::NT * 64;      // Frag units: hi image size
   const size_t lds = C::lds_bytes(args.nrows);
   if (lds > 160 * 1024) return -12;
   auto kern = sa_conv_gemm_kernel<T, CIN, COUT, SA, U>;
@@ -235,7 +256,7 @@ static int launch_cfg(const SaConvArgs& a, hipStream_t st) {
     attr_set = true;
   }
   dim3 grid(args.ntiles, a.B);
-  hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, args, (int)C::red_off(args.nrows));
+  hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, args, (int)C::tile_bytes(args.nrows));
   hipError_t e = hipGetLastError();
   return e == hipSuccess ? 0 : -(int)e;
 }
@@ -246,7 +267,8 @@ extern "C" int sa_conv_gemm_ntiles(int Lout, int U) { return sa_div_up(sa_div_up
 #define SA_CONV_CASE(CI, CO, S, UU)                                              \
   if (cin == CI && cout == CO && sa == S && u == UU)                             \
     return dtype == SA_BF16 ? launch_cfg<bf16_t, CI, CO, S, UU>(*a, st)          \
-                            : launch_cfg<float, CI, CO, S, UU>(*a, st);
+           : dtype == SA_BF16X3 ? launch_cfg<bf16x3_t, CI, CO, S, UU>(*a, st)    \
+                                : launch_cfg<float, CI, CO, S, UU>(*a, st);
 
 // C-ABI entry (see include/sa_hip.h).  Returns 0, or a negative hipError_t / errno.
 extern "C" int sa_conv_gemm(int dtype, int cin, int cout, int sa, int u, const SaConvArgs* a,

@@ -255,20 +255,31 @@ extern "C" int sa_wgrad1C(int dtype, const float* u, const void* v, float* slabs
   return e == hipSuccess ? 0 : -(int)e;
 }
 
-// dst[i] (=|+=) sum_k slabs[k][i]   (fixed order, double accumulate)
-__global__ void sa_sum_slabs_kernel(const float* __restrict__ slabs, float* __restrict__ dst,
-                                    int nslab, int n, int accumulate) {
-  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
-    double s = 0.0;
-    for (int k = 0; k < nslab; ++k) s += (double)slabs[(size_t)k * n + i];
-    dst[i] = accumulate ? dst[i] + (float)s : (float)s;
+// dst[i] (=|+=) sum_k slabs[k][i]   (fixed order, double accumulate; 16 outputs x 16 slab lanes)
+__global__ __launch_bounds__(256) void sa_sum_slabs_kernel(const float* __restrict__ slabs,
+                                                           float* __restrict__ dst, int nslab, int n,
+                                                           int accumulate) {
+  __shared__ double part[16][17];
+  const int o = threadIdx.x & 15, q = threadIdx.x >> 4, i = blockIdx.x * 16 + o;
+  double s = 0.0;
+  if (i < n) {
+#pragma unroll 4
+    for (int k = q; k < nslab; k += 16) s += (double)slabs[(size_t)k * n + i];
+  }
+  part[q][o] = s;
+  __syncthreads();
+  if (q == 0 && i < n) {
+    double t = 0.0;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) t += part[r][o];
+    dst[i] = accumulate ? dst[i] + (float)t : (float)t;
   }
 }
 
 extern "C" int sa_sum_slabs(const float* slabs, float* dst, int nslab, int n, int accumulate,
                             void* stream) {
   if (!slabs || !dst || nslab <= 0 || n <= 0) return -22;
-  hipLaunchKernelGGL(sa_sum_slabs_kernel, dim3(sa_div_up(n, 256)), dim3(256), 0,
+  hipLaunchKernelGGL(sa_sum_slabs_kernel, dim3(sa_div_up(n, 16)), dim3(256), 0,
                      reinterpret_cast<hipStream_t>(stream), slabs, dst, nslab, n, accumulate);
   hipError_t e = hipGetLastError();
   return e == hipSuccess ? 0 : -(int)e;

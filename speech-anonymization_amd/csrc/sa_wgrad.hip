@@ -45,6 +45,28 @@ __global__ void sa_pack_weights_kernel(const float* __restrict__ src, T* __restr
   }
 }
 
+// split image: hi = bf16(w) image followed by lo = bf16(w - hi) image (SA_BF16X3)
+__global__ void sa_pack_weights_split_kernel(const float* __restrict__ src, bf16_t* __restrict__ dst,
+                                             int ntaps, int K, int N, int sk, int sn, int st) {
+  constexpr int KS = 16, PER = 8;
+  const int total = ntaps * K * N;
+  const int NT = N / 32, KSTEPS = K / KS;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+    const int j = i % PER;
+    int r = i / PER;
+    const int lane = r % 64; r /= 64;
+    const int nt = r % NT; r /= NT;
+    const int ks = r % KSTEPS;
+    const int t = r / KSTEPS;
+    const int k = ks * KS + PER * (lane >> 5) + j;
+    const int n = nt * 32 + (lane & 31);
+    const float w = src[(size_t)k * sk + (size_t)n * sn + (size_t)t * st];
+    const bf16_t hi = (bf16_t)w;
+    dst[i] = hi;
+    dst[(size_t)total + i] = (bf16_t)(w - (float)hi);
+  }
+}
+
 extern "C" int sa_pack_weights(int dtype, const float* src, void* dst, int ntaps, int K, int N,
                                int sk, int sn, int st, void* stream) {
   if (!src || !dst || K % 16 || N % 32) return -22;
@@ -53,6 +75,9 @@ extern "C" int sa_pack_weights(int dtype, const float* src, void* dst, int ntaps
   const int grid = sa_div_up(total, 256) < 1024 ? sa_div_up(total, 256) : 1024;
   if (dtype == SA_BF16)
     hipLaunchKernelGGL(sa_pack_weights_kernel<bf16_t>, dim3(grid), dim3(256), 0, s, src,
+                       reinterpret_cast<bf16_t*>(dst), ntaps, K, N, sk, sn, st);
+  else if (dtype == SA_BF16X3)
+    hipLaunchKernelGGL(sa_pack_weights_split_kernel, dim3(grid), dim3(256), 0, s, src,
                        reinterpret_cast<bf16_t*>(dst), ntaps, K, N, sk, sn, st);
   else
     hipLaunchKernelGGL(sa_pack_weights_kernel<float>, dim3(grid), dim3(256), 0, s, src,
@@ -65,26 +90,38 @@ extern "C" int sa_pack_weights(int dtype, const float* src, void* dst, int ntaps
 // wgrad GEMM
 // ---------------------------------------------------------------------------------
 
-template <typename T, int C> struct WgPitch {
+template <typename LT, int C> struct WgPitch {
   // bf16: (pitch bytes / 4) mod 64 in {16, 48} makes the 4 rows of a tr16_b64 half-wave
   // block fall on disjoint bank windows; f32: any pitch is conflict free for ds_read_b32.
-  static constexpr int value = sizeof(T) == 2 ? (C >= 64 ? C + 32 : C) : C;
+  static constexpr int value = sizeof(LT) == 2 ? (C >= 64 ? C + 32 : C) : C;
 };
+
+// 8 consecutive k (rows) of one channel column per lane, from an untransposed [row][channel]
+// bf16 LDS tile: two ds_read_b64_tr_b16 (rows +0..3, +4..7).  `p` = this lane's block address.
+__device__ static inline bf16x8 sa_tr_frag(const bf16_t* p, int pitch) {
+  bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)(p));
+  bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(
+      (__attribute__((address_space(3))) bf16x4*)(p + 4 * pitch));
+  return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+}
 
 template <typename T, int CIN, int COUT, int SA, int U>
 __global__ __launch_bounds__(256) void sa_wgrad_kernel(SaWgradArgs a) {
-  typedef Tr<T> tr;
-  typedef typename tr::Frag Frag;
-  constexpr int VEC = tr::VEC, KS = tr::KS;
-  constexpr int KT = 64;                              // rows per LDS tile
-  constexpr int PA = WgPitch<T, CIN>::value, PB = WgPitch<T, COUT>::value;
+  typedef Pol<T> P;
+  typedef typename P::store_t S;
+  typedef typename P::lds_t LT;
+  typedef typename P::Frag Frag;
+  typedef Tr<S> tr;
+  constexpr int VEC = P::VEC, KS = P::KS, NPL = P::NPL;
+  constexpr int KT = NPL == 2 ? 32 : 64;              // rows per LDS tile
+  constexpr int PA = WgPitch<LT, CIN>::value, PB = WgPitch<LT, COUT>::value;
   constexpr int MT = CIN / 32, NT = COUT / 32;
   constexpr int WN = NT >= 4 ? 4 : NT, WM = 4 / WN;   // waves over n-tiles / m-tiles
   constexpr int MPW = (MT + WM - 1) / WM;             // m-tiles per wave
   constexpr int NPW = NT / WN;
   constexpr int CHA = CIN / VEC, RPA = 256 / CHA, CHB = COUT / VEC, RPB = 256 / CHB;
-  __shared__ __attribute__((aligned(16))) T At[KT * PA];
-  __shared__ __attribute__((aligned(16))) T Bt[KT * PB];
+  __shared__ __attribute__((aligned(16))) LT At[NPL * KT * PA];
+  __shared__ __attribute__((aligned(16))) LT Bt[NPL * KT * PB];
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int chunk = blockIdx.x, tap = blockIdx.y, b = blockIdx.z;
@@ -101,7 +138,6 @@ __global__ __launch_bounds__(256) void sa_wgrad_kernel(SaWgradArgs a) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
 
-  // prologue coefficients of this thread's input-channel chunk
   const int ca = tid % CHA, ra0 = tid / CHA, cb = tid % CHB, rb0 = tid / CHB;
   float s1[VEC], t1[VEC], s2[VEC], t2[VEC];
 #pragma unroll
@@ -112,19 +148,19 @@ __global__ __launch_bounds__(256) void sa_wgrad_kernel(SaWgradArgs a) {
     t2[j] = a.t2 ? a.t2[ca * VEC + j] : 0.0f;
   }
   const bool has1 = a.s1 != nullptr, has2 = a.s2 != nullptr, sw = a.swish != 0;
-  const T* xb = reinterpret_cast<const T*>(a.x) + (size_t)b * a.Lin * CIN + ca * VEC;
-  const T* yb = reinterpret_cast<const T*>(a.dy) + (size_t)b * a.Ldy * COUT + cb * VEC;
+  const S* xb = reinterpret_cast<const S*>(a.x) + (size_t)b * a.Lin * CIN + ca * VEC;
+  const S* yb = reinterpret_cast<const S*>(a.dy) + (size_t)b * a.Ldy * COUT + cb * VEC;
 
   for (int mt0 = mbeg; mt0 < mend; mt0 += KT) {
     // ---- stage KT rows of A (transformed) and dY; out-of-range rows are zero ----
     for (int r = ra0; r < KT; r += RPA) {
       const int m = mt0 + r, g = m * SA + off;
-      uint4 u = make_uint4(0, 0, 0, 0);
+      float f[VEC];
+#pragma unroll
+      for (int j = 0; j < VEC; ++j) f[j] = 0.0f;
       if (m < mend && g >= 0 && g < a.Lin) {
-        u = *reinterpret_cast<const uint4*>(xb + (size_t)g * CIN);
+        tr::unpack(*reinterpret_cast<const uint4*>(xb + (size_t)g * CIN), f);
         if (has1 || has2 || sw) {
-          float f[VEC];
-          tr::unpack(u, f);
 #pragma unroll
           for (int j = 0; j < VEC; ++j) {
             float v = f[j];
@@ -133,34 +169,49 @@ __global__ __launch_bounds__(256) void sa_wgrad_kernel(SaWgradArgs a) {
             if (has2) v = fmaf(v, s2[j], t2[j]);
             f[j] = v;
           }
-          u = tr::pack(f);
         }
       }
-      *reinterpret_cast<uint4*>(At + (size_t)r * PA + ca * VEC) = u;
+      LT* dst = At + (size_t)r * PA + ca * VEC;
+      if constexpr (NPL == 2) {
+        uint2 hi, lo;
+        sa_split4(f, hi, lo);
+        *reinterpret_cast<uint2*>(dst) = hi;
+        *reinterpret_cast<uint2*>(dst + KT * PA) = lo;
+      } else {
+        *reinterpret_cast<uint4*>(dst) = tr::pack(f);
+      }
     }
     for (int r = rb0; r < KT; r += RPB) {
       const int m = mt0 + r, g = m * U + ph;
       uint4 u = make_uint4(0, 0, 0, 0);
       if (m < mend && g < a.Ldy) u = *reinterpret_cast<const uint4*>(yb + (size_t)g * COUT);
-      *reinterpret_cast<uint4*>(Bt + (size_t)r * PB + cb * VEC) = u;
+      LT* dst = Bt + (size_t)r * PB + cb * VEC;
+      if constexpr (NPL == 2) {
+        float f[VEC];
+        tr::unpack(u, f);
+        uint2 hi, lo;
+        sa_split4(f, hi, lo);
+        *reinterpret_cast<uint2*>(dst) = hi;
+        *reinterpret_cast<uint2*>(dst + KT * PB) = lo;
+      } else {
+        *reinterpret_cast<uint4*>(dst) = u;
+      }
     }
     __syncthreads();
     // ---- MFMA over the KT rows ----
+    const int g4 = lane >> 4, i16 = lane & 15;
+    const int troff = (8 * (g4 >> 1) + (i16 >> 2));       // tr-read: row within the k-step block
+    const int tcoff = 16 * (g4 & 1) + 4 * (i16 & 3);      //          column within the 32-wide tile
 #pragma unroll 2
     for (int k0 = 0; k0 < KT; k0 += KS) {
-      Frag bfr[NPW];
+      Frag bfr[NPW], bfl[NPW];
 #pragma unroll
       for (int j = 0; j < NPW; ++j) {
         const int nt = wn + j * WN;
-        if constexpr (sizeof(T) == 2) {
-          const int g = lane >> 4, i = lane & 15;
-          const T* p = Bt + (size_t)(k0 + 8 * (g >> 1) + (i >> 2)) * PB + nt * 32 + 16 * (g & 1)
-                       + 4 * (i & 3);
-          bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(
-              (__attribute__((address_space(3))) bf16x4*)(p));
-          bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(
-              (__attribute__((address_space(3))) bf16x4*)(p + 4 * PB));
-          bfr[j] = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+        if constexpr (sizeof(LT) == 2) {
+          const LT* p = Bt + (size_t)(k0 + troff) * PB + nt * 32 + tcoff;
+          bfr[j] = sa_tr_frag(p, PB);
+          if constexpr (NPL == 2) bfl[j] = sa_tr_frag(p + KT * PB, PB);
         } else {
           bfr[j] = Bt[(size_t)(k0 + (lane >> 5)) * PB + nt * 32 + (lane & 31)];
         }
@@ -169,21 +220,28 @@ __global__ __launch_bounds__(256) void sa_wgrad_kernel(SaWgradArgs a) {
       for (int i2 = 0; i2 < MPW; ++i2) {
         const int mt = wm + i2 * WM;
         if (mt < MT) {
-          Frag af;
-          if constexpr (sizeof(T) == 2) {
-            const int g = lane >> 4, i = lane & 15;
-            const T* p = At + (size_t)(k0 + 8 * (g >> 1) + (i >> 2)) * PA + mt * 32
-                         + 16 * (g & 1) + 4 * (i & 3);
-            bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(
-                (__attribute__((address_space(3))) bf16x4*)(p));
-            bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(
-                (__attribute__((address_space(3))) bf16x4*)(p + 4 * PA));
-            af = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
-          } else {
-            af = At[(size_t)(k0 + (lane >> 5)) * PA + mt * 32 + (lane & 31)];
-          }
+          if constexpr (sizeof(LT) == 2) {
+            const LT* p = At + (size_t)(k0 + troff) * PA + mt * 32 + tcoff;
+            const Frag af = sa_tr_frag(p, PA);
+            if constexpr (NPL == 2) {
+              const Frag al = sa_tr_frag(p + KT * PA, PA);
 #pragma unroll
-          for (int j = 0; j < NPW; ++j) acc[i2][j] = tr::mfma(af, bfr[j], acc[i2][j]);
+              for (int j = 0; j < NPW; ++j) {
+                acc[i2][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bfr[j], acc[i2][j], 0, 0, 0);
+                acc[i2][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, bfl[j], acc[i2][j], 0, 0, 0);
+                acc[i2][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, bfr[j], acc[i2][j], 0, 0, 0);
+              }
+            } else {
+#pragma unroll
+              for (int j = 0; j < NPW; ++j)
+                acc[i2][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, bfr[j], acc[i2][j], 0, 0, 0);
+            }
+          } else {
+            const Frag af = At[(size_t)(k0 + (lane >> 5)) * PA + mt * 32 + (lane & 31)];
+#pragma unroll
+            for (int j = 0; j < NPW; ++j)
+              acc[i2][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af, bfr[j], acc[i2][j], 0, 0, 0);
+          }
         }
       }
     }
@@ -218,7 +276,8 @@ static int launch_wgrad(const SaWgradArgs& a, hipStream_t st) {
 #define SA_WG_CASE(CI, CO, S, UU)                                               \
   if (cin == CI && cout == CO && sa == S && u == UU)                            \
     return dtype == SA_BF16 ? launch_wgrad<bf16_t, CI, CO, S, UU>(*a, st)       \
-                            : launch_wgrad<float, CI, CO, S, UU>(*a, st);
+           : dtype == SA_BF16X3 ? launch_wgrad<bf16x3_t, CI, CO, S, UU>(*a, st) \
+                                : launch_wgrad<float, CI, CO, S, UU>(*a, st);
 
 extern "C" int sa_wgrad(int dtype, int cin, int cout, int sa, int u, const SaWgradArgs* a,
                         void* stream) {

@@ -70,10 +70,17 @@ class _Profile:
 PROFILE = _Profile()
 
 
-def pack_weights(w, kind, dtype):
+# precision modes of the MFMA kernels: name -> (activation storage dtype, kernel dtype code)
+PRECISIONS = {"f32": (torch.float32, L.F32), "bf16": (torch.bfloat16, L.BF16),
+              "bf16x3": (torch.float32, L.BF16X3)}
+
+
+def pack_weights(w, kind, dtype, code=None):
     """w: fp32 parameter in PyTorch layout.  kind: conv_fwd | conv_dgrad | convT_fwd |
-    convT_dgrad.  Returns the fragment-major operand image (flat tensor of `dtype`)."""
+    convT_dgrad.  Returns the fragment-major operand image (flat tensor; for code BF16X3 the
+    hi image followed by the lo image, both bf16)."""
     lib = L.load()
+    code = L.dt_code(dtype) if code is None else code
     if kind in ("conv_fwd", "conv_dgrad"):
         Cout, Cin, Kw = w.shape
         if kind == "conv_fwd":
@@ -86,14 +93,17 @@ def pack_weights(w, kind, dtype):
             K, N, sk, sn = Cin, Cout, Cout * Kw, Kw
         else:
             K, N, sk, sn = Cout, Cin, Kw, Cout * Kw
-    out = torch.empty(Kw * K * N, dtype=dtype, device=w.device)
-    L.check(lib.sa_pack_weights(L.dt_code(dtype), _f(w), _f(out), Kw, K, N, sk, sn, 1, L.stream()),
+    if code == L.BF16X3:
+        out = torch.empty(2 * Kw * K * N, dtype=torch.bfloat16, device=w.device)
+    else:
+        out = torch.empty(Kw * K * N, dtype=dtype, device=w.device)
+    L.check(lib.sa_pack_weights(code, _f(w), _f(out), Kw, K, N, sk, sn, 1, L.stream()),
             "sa_pack_weights")
     return out
 
 
 def conv_gemm(x, wp, bias, cin, cout, sa, u, phases, Lout, s1=None, t1=None, s2=None, t2=None,
-              swish=False, relu=False, want_stats=False, out=None):
+              swish=False, relu=False, want_stats=False, out=None, code=None):
     """x [B, Lin, cin] -> y [B, Lout, cout] (+ per-tile partial stats [B, ntiles, cout, 2])."""
     lib = L.load()
     B, Lin, _ = x.shape
@@ -108,7 +118,8 @@ def conv_gemm(x, wp, bias, cin, cout, sa, u, phases, Lout, s1=None, t1=None, s2=
     a.B, a.Lin, a.Lout = B, Lin, Lout
     a.taps = L.make_taps(phases)
     e0 = PROFILE.start(f"conv_gemm({cin},{cout},{sa},{u})") if PROFILE.key else None
-    L.check(lib.sa_conv_gemm(L.dt_code(x.dtype), cin, cout, sa, u, C.byref(a), L.stream()),
+    L.check(lib.sa_conv_gemm(L.dt_code(x.dtype) if code is None else code, cin, cout, sa, u,
+                             C.byref(a), L.stream()),
             f"sa_conv_gemm({cin},{cout},{sa},{u})")
     if e0 is not None:
         ntap = sum(len(p) for p in phases)
@@ -119,7 +130,7 @@ def conv_gemm(x, wp, bias, cin, cout, sa, u, phases, Lout, s1=None, t1=None, s2=
 
 
 def wgrad(x, dy, cin, cout, sa, u, taps, Mrows, dst, dst_strides, s1=None, t1=None, s2=None,
-          t2=None, swish=False, accumulate=False, target_wgs=768):
+          t2=None, swish=False, accumulate=False, target_wgs=768, code=None):
     """taps: list of (row_offset, phase) per weight tap.  dst: fp32 parameter-gradient tensor in
     PyTorch layout; dst_strides = (s_ci, s_co, s_tap)."""
     lib = L.load()
@@ -136,7 +147,8 @@ def wgrad(x, dy, cin, cout, sa, u, taps, Mrows, dst, dst_strides, s1=None, t1=No
     a.B, a.Lin, a.Ldy, a.Mrows, a.chunk, a.nchunk, a.ntaps = B, Lin, Ldy, Mrows, chunk, nchunk, nt
     for i, (off, ph) in enumerate(taps):
         a.off[i], a.ph[i] = off, ph
-    L.check(lib.sa_wgrad(L.dt_code(x.dtype), cin, cout, sa, u, C.byref(a), L.stream()),
+    L.check(lib.sa_wgrad(L.dt_code(x.dtype) if code is None else code, cin, cout, sa, u,
+                         C.byref(a), L.stream()),
             f"sa_wgrad({cin},{cout},{sa},{u})")
     sk, sn, st = dst_strides
     L.check(lib.sa_wgrad_reduce(_f(slabs), _f(dst), B * nchunk, nt, cin, cout, sk, sn, st,

@@ -10,6 +10,11 @@ def test_train_step_fp32_matches_oracle():
     smoke_step.run(torch.float32)
 
 
+def test_train_step_bf16x3_matches_oracle():
+    from tests import smoke_step
+    smoke_step.run("bf16x3")
+
+
 def test_train_step_bf16_runs_and_tracks_oracle():
     from tests import smoke_step
     smoke_step.run(torch.bfloat16)
