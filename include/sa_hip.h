@@ -37,7 +37,7 @@ extern "C" {
  * rows outside [0,Lin) are zero.  P = prologue: v*s1[b][ci]+t1[b][ci] -> x*sigmoid(x) if swish
  * -> v*s2[ci]+t2[ci] (any pointer may be NULL).  Epilogue: +bias, ReLU if relu, store, and if
  * stats != NULL per-tile partial (sum, sumsq) of the stored values -> stats[B][ntiles][COUT][2]
- * with ntiles = sa_conv_gemm_ntiles(Lout, U). */
+ * with ntiles = sa_conv_gemm_ntiles(cin, cout, u, Lout). */
 typedef struct SaTaps {
   int ntaps[2];
   int off[2][SA_MAX_TAPS];
@@ -60,7 +60,8 @@ typedef struct SaConvArgs {
 } SaConvArgs;
 
 int sa_conv_gemm(int dtype, int cin, int cout, int sa, int u, const SaConvArgs* a, void* stream);
-int sa_conv_gemm_ntiles(int Lout, int U);
+int sa_conv_gemm_ntiles(int cin, int cout, int u, int Lout);
+int sa_conv_gemm_set_tile_rows(int rows);   /* tuning knob: 0 (default policy), 64 or 128 */
 
 /* fp32 master weights -> fragment-major MFMA operand image (K = GEMM reduction channels,
  * N = produced channels; element W(t,k,n) = src[k*sk + n*sn + t*st]).
@@ -71,8 +72,9 @@ int sa_pack_weights(int dtype, const float* src, void* dst, int ntaps, int K, in
 
 /* ---- weight gradients (sa_wgrad.hip) --------------------------------------------------
  * dW[t][ci][co] = sum_b sum_{m<Mrows} P(x)[b, m*SA+off[t], ci] * dy[b, m*U+ph[t], co];
- * grid (nchunk, ntaps, B), each workgroup covers `chunk` (multiple of 64) base rows and writes
- * slabs[b][chunk][t][CIN][COUT]; sa_wgrad_reduce sums them in a fixed order into
+ * grid (nchunk, channel sub-blocks, B): each workgroup covers `chunk` (multiple of 64) base rows,
+ * every tap, and one (<=64 x <=64) channel sub-block; slabs[b][chunk][kw][t][CIN][COUT] with
+ * kw < sa_wgrad_kw(cin, cout); sa_wgrad_reduce sums the B*nchunk*kw slabs in a fixed order into
  * dst[ci*sk + co*sn + t*st]. */
 typedef struct SaWgradArgs {
   const void* x;
@@ -84,6 +86,7 @@ typedef struct SaWgradArgs {
 } SaWgradArgs;
 
 int sa_wgrad(int dtype, int cin, int cout, int sa, int u, const SaWgradArgs* a, void* stream);
+int sa_wgrad_kw(int cin, int cout);
 int sa_wgrad_reduce(const float* slabs, float* dst, int nslab, int ntaps, int cin, int cout, int sk,
                     int sn, int st, int accumulate, void* stream);
 

@@ -18,7 +18,9 @@
 //              as a per-tile partial slab (deterministic two-level reduction; no atomics).
 #include "sa_common.h"
 
-template <typename T, int CIN, int COUT, int SA, int U>
+#define SA_MAX_HALO 16      // max (largest - smallest) tap row offset the prologue is sized for
+
+template <typename T, int CIN, int COUT, int SA, int U, int TM>
 struct ConvCfg {
   typedef Pol<T> P;
   typedef typename P::store_t S;
@@ -28,7 +30,7 @@ struct ConvCfg {
   static constexpr int KSTEPS = CIN / KS;
   static constexpr int NT = COUT / 32;
   static constexpr int VT = NT * U;                 // virtual n-tiles (phase, n-tile)
-  static constexpr int BMB = 128 / U;               // base rows per workgroup
+  static constexpr int BMB = TM / U;                // base rows per workgroup (TM output rows)
   static constexpr int WN = VT >= 4 ? 4 : VT;       // waves along N
   static constexpr int WM = 4 / WN;                 // waves along M
   static constexpr int VPW = VT / WN;               // virtual n-tiles per wave
@@ -43,16 +45,16 @@ struct ConvCfg {
   static_assert(MT >= 1 && VT % WN == 0, "tile shape");
   static size_t tile_bytes(int nrows) {
     size_t a = (size_t)P::NPL * nrows * APITCH * sizeof(LT);
-    size_t o = (size_t)128 * OPITCH * sizeof(S);
+    size_t o = (size_t)TM * OPITCH * sizeof(S);
     size_t m = a > o ? a : o;
     return (m + 15) & ~(size_t)15;
   }
   static size_t lds_bytes(int nrows) { return tile_bytes(nrows) + (size_t)RPPO * COUT * 2 * sizeof(float); }
 };
 
-template <typename T, int CIN, int COUT, int SA, int U>
+template <typename T, int CIN, int COUT, int SA, int U, int TM>
 __global__ __launch_bounds__(256) void sa_conv_gemm_kernel(SaConvArgs a, int red_off) {
-  typedef ConvCfg<T, CIN, COUT, SA, U> C;
+  typedef ConvCfg<T, CIN, COUT, SA, U, TM> C;
   typedef Pol<T> P;
   typedef typename P::store_t S;
   typedef typename P::lds_t LT;
@@ -83,14 +85,23 @@ __global__ __launch_bounds__(256) void sa_conv_gemm_kernel(SaConvArgs a, int red
     const bool has1 = a.s1 != nullptr, has2 = a.s2 != nullptr, sw = a.swish != 0;
     const S* xb = reinterpret_cast<const S*>(a.x) + (size_t)b * a.Lin * CIN + c * VEC;
     const int gbase = m0 * SA + a.rowmin;
-    for (int r = r0; r < a.nrows; r += C::RPPI) {
-      const int g = gbase + r;
-      float f[VEC];
+    // All row loads of this thread are issued before the first one is consumed (a
+    // load -> transform -> LDS-write loop would pay one HBM round trip per iteration).
+    constexpr int NIT = ((C::BMB - 1) * SA + 1 + SA_MAX_HALO + C::RPPI - 1) / C::RPPI;
+    uint4 raw[NIT];
 #pragma unroll
-      for (int j = 0; j < VEC; ++j) f[j] = 0.0f;
-      if (g >= 0 && g < a.Lin) {
-        tr::unpack(*reinterpret_cast<const uint4*>(xb + (size_t)g * CIN), f);
-        if (has1 || has2 || sw) {
+    for (int i = 0; i < NIT; ++i) {
+      const int r = r0 + i * C::RPPI, g = gbase + r;
+      raw[i] = make_uint4(0, 0, 0, 0);
+      if (r < a.nrows && g >= 0 && g < a.Lin) raw[i] = *reinterpret_cast<const uint4*>(xb + (size_t)g * CIN);
+    }
+#pragma unroll
+    for (int i = 0; i < NIT; ++i) {
+      const int r = r0 + i * C::RPPI, g = gbase + r;
+      if (r < a.nrows) {
+        float f[VEC];
+        tr::unpack(raw[i], f);
+        if ((has1 || has2 || sw) && g >= 0 && g < a.Lin) {
 #pragma unroll
           for (int j = 0; j < VEC; ++j) {
             float v = f[j];
@@ -100,18 +111,18 @@ __global__ __launch_bounds__(256) void sa_conv_gemm_kernel(SaConvArgs a, int red
             f[j] = v;
           }
         }
-      }
-      LT* dst = As + (size_t)r * C::APITCH + c * VEC;
-      if constexpr (P::NPL == 2) {
-        uint2 hi, lo;
-        sa_split4(f, hi, lo);
-        *reinterpret_cast<uint2*>(dst) = hi;
-        *reinterpret_cast<uint2*>(dst + plane) = lo;
-      } else if constexpr (sizeof(LT) == 2) {
-        *reinterpret_cast<uint4*>(dst) = tr::pack(f);
-      } else {
-        float* d = reinterpret_cast<float*>(dst);
-        d[0] = f[0]; d[1] = f[1]; d[2] = f[2]; d[3] = f[3];
+        LT* dst = As + (size_t)r * C::APITCH + c * VEC;
+        if constexpr (P::NPL == 2) {
+          uint2 hi, lo;
+          sa_split4(f, hi, lo);
+          *reinterpret_cast<uint2*>(dst) = hi;
+          *reinterpret_cast<uint2*>(dst + plane) = lo;
+        } else if constexpr (sizeof(LT) == 2) {
+          *reinterpret_cast<uint4*>(dst) = tr::pack(f);
+        } else {
+          float* d = reinterpret_cast<float*>(dst);
+          d[0] = f[0]; d[1] = f[1]; d[2] = f[2]; d[3] = f[3];
+        }
       }
     }
   }
@@ -127,39 +138,60 @@ __global__ __launch_bounds__(256) void sa_conv_gemm_kernel(SaConvArgs a, int red
 #pragma unroll
       for (int i = 0; i < 16; ++i) acc[v][mt][i] = 0.0f;
 
+  // Weight fragments (B operand) come straight from global memory (L2-resident image); they are
+  // software-pipelined one group of KU k-steps ahead in registers so their latency hides
+  // behind the previous group's MFMAs (two statically indexed register buffers, ping-pong).
+  constexpr int KUP = P::NPL == 2 ? 4 : 8;
+  constexpr int KU = C::KSTEPS < KUP ? C::KSTEPS : KUP;
+  constexpr int GPT = C::KSTEPS / KU;                // groups per tap
+  static_assert(C::KSTEPS % KU == 0, "k-steps per tap must be a multiple of the prefetch group");
   const Frag* wp = reinterpret_cast<const Frag*>(a.wp);
 #pragma unroll
   for (int v = 0; v < C::VPW; ++v) {
     const int vt = wn + v * C::WN;
     const int ph = vt / C::NT, nt = vt % C::NT;
-    const int ntaps = a.taps.ntaps[ph];
-    for (int ti = 0; ti < ntaps; ++ti) {
-      const int off = a.taps.off[ph][ti] - a.rowmin;
-      const Frag* wt = wp + ((size_t)a.taps.widx[ph][ti] * C::KSTEPS * C::NT + nt) * 64 + lane;
-      const LT* arow = As + (size_t)((wm * C::MT * 32 + (lane & 31)) * SA + off) * C::APITCH
-                       + (lane >> 5) * (C::KS / 2);
-#pragma unroll 4
-      for (int ks = 0; ks < C::KSTEPS; ++ks) {
-        const Frag bf = wt[(size_t)ks * C::NT * 64];
-        if constexpr (P::NPL == 2) {
-          const Frag bl = wt[(size_t)a.wlo_off + (size_t)ks * C::NT * 64];
+    const int G = a.taps.ntaps[ph] * GPT;
+    const LT* abase = As + (size_t)((wm * C::MT * 32 + (lane & 31)) * SA - a.rowmin) * C::APITCH
+                      + (lane >> 5) * (C::KS / 2);
+    auto load_group = [&](Frag (&dst)[P::NPL][KU], int g) {
+      const int ti = g / GPT, kg = g % GPT;
+      const Frag* wt = wp + (((size_t)a.taps.widx[ph][ti] * C::KSTEPS + kg * KU) * C::NT + nt) * 64 + lane;
 #pragma unroll
-          for (int mt = 0; mt < C::MT; ++mt) {
-            const LT* ap = arow + (size_t)mt * 32 * SA * C::APITCH + ks * C::KS;
+      for (int ku = 0; ku < KU; ++ku) {
+        dst[0][ku] = wt[(size_t)ku * C::NT * 64];
+        if constexpr (P::NPL == 2) dst[1][ku] = wt[(size_t)a.wlo_off + (size_t)ku * C::NT * 64];
+      }
+    };
+    auto compute_group = [&](const Frag (&bq)[P::NPL][KU], int g) {
+      const int ti = g / GPT, kg = g % GPT;
+      const LT* arow = abase + (size_t)a.taps.off[ph][ti] * C::APITCH
+                       + kg * KU * C::KS;
+#pragma unroll
+      for (int ku = 0; ku < KU; ++ku) {
+#pragma unroll
+        for (int mt = 0; mt < C::MT; ++mt) {
+          const LT* ap = arow + (size_t)mt * 32 * SA * C::APITCH + ku * C::KS;
+          if constexpr (P::NPL == 2) {
             const Frag ah = *reinterpret_cast<const Frag*>(ap);
             const Frag al = *reinterpret_cast<const Frag*>(ap + plane);
-            acc[v][mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bf, acc[v][mt], 0, 0, 0);
-            acc[v][mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc[v][mt], 0, 0, 0);
-            acc[v][mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bf, acc[v][mt], 0, 0, 0);
-          }
-        } else {
-#pragma unroll
-          for (int mt = 0; mt < C::MT; ++mt) {
-            const Frag af = *reinterpret_cast<const Frag*>(arow + (size_t)mt * 32 * SA * C::APITCH
-                                                           + ks * C::KS);
-            acc[v][mt] = Tr<LT>::mfma(af, bf, acc[v][mt]);
+            acc[v][mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bq[0][ku], acc[v][mt], 0, 0, 0);
+            acc[v][mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bq[1][ku], acc[v][mt], 0, 0, 0);
+            acc[v][mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bq[0][ku], acc[v][mt], 0, 0, 0);
+          } else {
+            const Frag af = *reinterpret_cast<const Frag*>(ap);
+            acc[v][mt] = Tr<LT>::mfma(af, bq[0][ku], acc[v][mt]);
           }
         }
+      }
+    };
+    Frag b0[P::NPL][KU], b1[P::NPL][KU];
+    load_group(b0, 0);
+    for (int g = 0; g < G; g += 2) {
+      if (g + 1 < G) load_group(b1, g + 1);
+      compute_group(b0, g);
+      if (g + 1 < G) {
+        if (g + 2 < G) load_group(b0, g + 2);
+        compute_group(b1, g + 1);
       }
     }
   }
@@ -191,7 +223,7 @@ __global__ __launch_bounds__(256) void sa_conv_gemm_kernel(SaConvArgs a, int red
     for (int j = 0; j < OVEC; ++j) { ssum[j] = 0.0f; ssq[j] = 0.0f; }
     S* yb = reinterpret_cast<S*>(a.y) + (size_t)b * a.Lout * COUT + c * OVEC;
     const int o0 = m0 * U;
-    for (int r = r0; r < 128; r += C::RPPO) {
+    for (int r = r0; r < TM; r += C::RPPO) {
       const int o = o0 + r;
       if (o < a.Lout) {
         const uint4 u = *reinterpret_cast<const uint4*>(Os + (size_t)r * C::OPITCH + c * OVEC);
@@ -226,9 +258,9 @@ __global__ __launch_bounds__(256) void sa_conv_gemm_kernel(SaConvArgs a, int red
   }
 }
 
-template <typename T, int CIN, int COUT, int SA, int U>
+template <typename T, int CIN, int COUT, int SA, int U, int TM>
 static int launch_cfg(const SaConvArgs& a, hipStream_t st) {
-  typedef ConvCfg<T, CIN, COUT, SA, U> C;
+  typedef ConvCfg<T, CIN, COUT, SA, U, TM> C;
   SaConvArgs args = a;
   args.ntiles = sa_div_up(sa_div_up(a.Lout, U), C::BMB);
   // host-side shape check: every LDS row the main loop touches must be staged
@@ -238,7 +270,7 @@ static int launch_cfg(const SaConvArgs& a, hipStream_t st) {
       omin = a.taps.off[ph][t] < omin ? a.taps.off[ph][t] : omin;
       omax = a.taps.off[ph][t] > omax ? a.taps.off[ph][t] : omax;
     }
-  if (omin > omax) return -22;
+  if (omin > omax || omax - omin > SA_MAX_HALO) return -22;
   int wmax = 0;
   for (int ph = 0; ph < U; ++ph)
     for (int t = 0; t < a.taps.ntaps[ph]; ++t) wmax = a.taps.widx[ph][t] > wmax ? a.taps.widx[ph][t] : wmax;
@@ -247,7 +279,7 @@ static int launch_cfg(const SaConvArgs& a, hipStream_t st) {
   args.wlo_off = (wmax + 1) * C::KSTEPS * C::NT * 64;      // Frag units: hi image size
   const size_t lds = C::lds_bytes(args.nrows);
   if (lds > 160 * 1024) return -12;
-  auto kern = sa_conv_gemm_kernel<T, CIN, COUT, SA, U>;
+  auto kern = sa_conv_gemm_kernel<T, CIN, COUT, SA, U, TM>;
   static bool attr_set = false;
   if (!attr_set) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
@@ -261,14 +293,43 @@ static int launch_cfg(const SaConvArgs& a, hipStream_t st) {
   return e == hipSuccess ? 0 : -(int)e;
 }
 
+// Output rows per workgroup.  64-row tiles keep 4-6 workgroups resident per CU so that one
+// workgroup's HBM staging / epilogue overlaps another's MFMA phase (the 128-row tile leaves
+// only 2-3 resident and showed ~60 % of the launch outside the MFMA loop); the 64->32 U=2 layer
+// needs 128 rows to give every wave a full 32-row m-tile.  sa_conv_gemm_set_tile_rows() is a
+// tuning knob (0 = default policy).
+static int g_tile_rows = 0;
+extern "C" int sa_conv_gemm_set_tile_rows(int rows) {
+  if (rows != 0 && rows != 64 && rows != 128) return -22;
+  g_tile_rows = rows;
+  return 0;
+}
+static int tile_rows(int cin, int cout, int u) {
+  if (cin == 64 && cout == 32 && u == 2) return 128;
+  return g_tile_rows ? g_tile_rows : 64;
+}
+
 // number of (sum, sumsq) partial tiles per utterance the epilogue writes
-extern "C" int sa_conv_gemm_ntiles(int Lout, int U) { return sa_div_up(sa_div_up(Lout, U), 128 / U); }
+extern "C" int sa_conv_gemm_ntiles(int cin, int cout, int u, int Lout) {
+  const int tm = tile_rows(cin, cout, u);
+  return sa_div_up(sa_div_up(Lout, u), tm / u);
+}
+
+template <typename T, int CI, int CO, int S, int UU>
+static int launch_tm(const SaConvArgs& a, hipStream_t st) {
+  if constexpr (CI == 64 && CO == 32 && UU == 2) {
+    return launch_cfg<T, CI, CO, S, UU, 128>(a, st);
+  } else {
+    return tile_rows(CI, CO, UU) == 64 ? launch_cfg<T, CI, CO, S, UU, 64>(a, st)
+                                       : launch_cfg<T, CI, CO, S, UU, 128>(a, st);
+  }
+}
 
 #define SA_CONV_CASE(CI, CO, S, UU)                                              \
   if (cin == CI && cout == CO && sa == S && u == UU)                             \
-    return dtype == SA_BF16 ? launch_cfg<bf16_t, CI, CO, S, UU>(*a, st)          \
-           : dtype == SA_BF16X3 ? launch_cfg<bf16x3_t, CI, CO, S, UU>(*a, st)    \
-                                : launch_cfg<float, CI, CO, S, UU>(*a, st);
+    return dtype == SA_BF16 ? launch_tm<bf16_t, CI, CO, S, UU>(*a, st)           \
+           : dtype == SA_BF16X3 ? launch_tm<bf16x3_t, CI, CO, S, UU>(*a, st)     \
+                                : launch_tm<float, CI, CO, S, UU>(*a, st);
 
 // C-ABI entry (see include/sa_hip.h).  Returns 0, or a negative hipError_t / errno.
 extern "C" int sa_conv_gemm(int dtype, int cin, int cout, int sa, int u, const SaConvArgs* a,

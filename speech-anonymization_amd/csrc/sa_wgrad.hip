@@ -96,151 +96,188 @@ template <typename LT, int C> struct WgPitch {
   static constexpr int value = sizeof(LT) == 2 ? (C >= 64 ? C + 32 : C) : C;
 };
 
-// 8 consecutive k (rows) of one channel column per lane, from an untransposed [row][channel]
-// bf16 LDS tile: two ds_read_b64_tr_b16 (rows +0..3, +4..7).  `p` = this lane's block address.
-__device__ static inline bf16x8 sa_tr_frag(const bf16_t* p, int pitch) {
+// 8 consecutive k (tile rows k, k+1, .. at row stride `rs` elements) of one channel column per
+// lane, from an untransposed [row][channel] bf16 LDS tile: two ds_read_b64_tr_b16.
+// `p` = this lane's block address (its row q = (lane&15)>>2, its 4-column group).
+__device__ static inline bf16x8 sa_tr_frag(const bf16_t* p, int rs) {
   bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)(p));
   bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(
-      (__attribute__((address_space(3))) bf16x4*)(p + 4 * pitch));
+      (__attribute__((address_space(3))) bf16x4*)(p + 4 * rs));
   return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
 }
 
+// One workgroup = (utterance b, row chunk, MS x NS channel sub-block) and ALL taps: the
+// (transformed) A rows and the dY rows are staged once per K-tile and reused by every tap (a
+// tap is a row offset into the A tile).  Wave w owns the 32x32 output pair (mt, nt) =
+// (w % NP / NT, w % NP % NT) for all taps (5 accumulators) and, when the sub-block has fewer
+// than 4 pairs, the k-steps ks = w / NP (mod KW).  HBM loads of K-tile i+1 are in flight (in
+// registers) while tile i is in the MFMAs.
+template <typename T, int CIN, int COUT, int SA, int U>
+struct WgCfg {
+  typedef Pol<T> P;
+  typedef typename P::lds_t LT;
+  static constexpr int MS = CIN < 64 ? CIN : 64, NS = COUT < 64 ? COUT : 64;
+  static constexpr int MT = MS / 32, NT = NS / 32, NP = MT * NT, KW = 4 / NP;
+  static constexpr int KT = (P::NPL == 2 || sizeof(typename P::store_t) == 4) ? 32 : 64;
+  static constexpr int HALO = 8;                                   // max tap offset spread
+  static constexpr int RA = KT * SA + HALO, RB = KT * U;           // staged rows
+  static constexpr int PA = WgPitch<LT, MS>::value, PB = WgPitch<LT, NS>::value;
+  static constexpr int CHA = MS / P::VEC, CHB = NS / P::VEC;       // 16-byte chunks per row
+  static constexpr int NITA = (RA * CHA + 255) / 256, NITB = (RB * CHB + 255) / 256;
+};
+
 template <typename T, int CIN, int COUT, int SA, int U>
 __global__ __launch_bounds__(256) void sa_wgrad_kernel(SaWgradArgs a) {
+  typedef WgCfg<T, CIN, COUT, SA, U> C;
   typedef Pol<T> P;
   typedef typename P::store_t S;
   typedef typename P::lds_t LT;
   typedef typename P::Frag Frag;
   typedef Tr<S> tr;
-  constexpr int VEC = P::VEC, KS = P::KS, NPL = P::NPL;
-  constexpr int KT = NPL == 2 ? 32 : 64;              // rows per LDS tile
-  constexpr int PA = WgPitch<LT, CIN>::value, PB = WgPitch<LT, COUT>::value;
-  constexpr int MT = CIN / 32, NT = COUT / 32;
-  constexpr int WN = NT >= 4 ? 4 : NT, WM = 4 / WN;   // waves over n-tiles / m-tiles
-  constexpr int MPW = (MT + WM - 1) / WM;             // m-tiles per wave
-  constexpr int NPW = NT / WN;
-  constexpr int CHA = CIN / VEC, RPA = 256 / CHA, CHB = COUT / VEC, RPB = 256 / CHB;
-  __shared__ __attribute__((aligned(16))) LT At[NPL * KT * PA];
-  __shared__ __attribute__((aligned(16))) LT Bt[NPL * KT * PB];
+  constexpr int VEC = P::VEC, KS = P::KS, NPL = P::NPL, KT = C::KT;
+  constexpr int PA = C::PA, PB = C::PB;
+  __shared__ __attribute__((aligned(16))) LT At[NPL * C::RA * PA];
+  __shared__ __attribute__((aligned(16))) LT Bt[NPL * C::RB * PB];
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int chunk = blockIdx.x, tap = blockIdx.y, b = blockIdx.z;
-  const int off = a.off[tap], ph = a.ph[tap];
+  const int chunk = blockIdx.x, sub = blockIdx.y, b = blockIdx.z;
+  const int cm0 = (sub / (COUT / C::NS)) * C::MS, cn0 = (sub % (COUT / C::NS)) * C::NS;
   const int mbeg = chunk * a.chunk;
   int mend = mbeg + a.chunk; if (mend > a.Mrows) mend = a.Mrows;
+  int offmin = a.off[0];
+  for (int t = 1; t < a.ntaps; ++t) offmin = a.off[t] < offmin ? a.off[t] : offmin;
 
-  const int wn = wave % WN, wm = wave / WN;
-  f32x16 acc[MPW][NPW];
+  const int pair = wave % C::NP, kw = wave / C::NP;
+  const int mt = pair / C::NT, nt = pair % C::NT;
+  f32x16 acc[SA_MAX_TAPS];
 #pragma unroll
-  for (int i = 0; i < MPW; ++i)
+  for (int t = 0; t < SA_MAX_TAPS; ++t)
 #pragma unroll
-    for (int j = 0; j < NPW; ++j)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+    for (int r = 0; r < 16; ++r) acc[t][r] = 0.0f;
 
-  const int ca = tid % CHA, ra0 = tid / CHA, cb = tid % CHB, rb0 = tid / CHB;
-  float s1[VEC], t1[VEC], s2[VEC], t2[VEC];
+  // prologue coefficients: 256 % CHA == 0, so a thread stages the same 16-byte channel chunk
+  // in every iteration slot and its coefficients live in registers
+  static_assert(256 % C::CHA == 0 && 256 % C::CHB == 0, "chunk column must be fixed per thread");
+  const bool has1 = a.s1 != nullptr, has2 = a.s2 != nullptr, sw = a.swish != 0;
+  float s1r[VEC], t1r[VEC], s2r[VEC], t2r[VEC];
 #pragma unroll
   for (int j = 0; j < VEC; ++j) {
-    s1[j] = a.s1 ? a.s1[(size_t)b * CIN + ca * VEC + j] : 1.0f;
-    t1[j] = a.t1 ? a.t1[(size_t)b * CIN + ca * VEC + j] : 0.0f;
-    s2[j] = a.s2 ? a.s2[ca * VEC + j] : 1.0f;
-    t2[j] = a.t2 ? a.t2[ca * VEC + j] : 0.0f;
+    const int ch = cm0 + (tid % C::CHA) * VEC + j;
+    s1r[j] = has1 ? a.s1[(size_t)b * CIN + ch] : 1.0f;
+    t1r[j] = has1 ? a.t1[(size_t)b * CIN + ch] : 0.0f;
+    s2r[j] = has2 ? a.s2[ch] : 1.0f;
+    t2r[j] = has2 ? a.t2[ch] : 0.0f;
   }
-  const bool has1 = a.s1 != nullptr, has2 = a.s2 != nullptr, sw = a.swish != 0;
-  const S* xb = reinterpret_cast<const S*>(a.x) + (size_t)b * a.Lin * CIN + ca * VEC;
-  const S* yb = reinterpret_cast<const S*>(a.dy) + (size_t)b * a.Ldy * COUT + cb * VEC;
+  const S* xb = reinterpret_cast<const S*>(a.x) + (size_t)b * a.Lin * CIN + cm0;
+  const S* yb = reinterpret_cast<const S*>(a.dy) + (size_t)b * a.Ldy * COUT + cn0;
+  const int dyend = mend * U < a.Ldy ? mend * U : a.Ldy;
 
-  for (int mt0 = mbeg; mt0 < mend; mt0 += KT) {
-    // ---- stage KT rows of A (transformed) and dY; out-of-range rows are zero ----
-    for (int r = ra0; r < KT; r += RPA) {
-      const int m = mt0 + r, g = m * SA + off;
-      float f[VEC];
+  uint4 rawA[C::NITA], rawB[C::NITB];
+  auto issue = [&](int m0) {
 #pragma unroll
-      for (int j = 0; j < VEC; ++j) f[j] = 0.0f;
-      if (m < mend && g >= 0 && g < a.Lin) {
-        tr::unpack(*reinterpret_cast<const uint4*>(xb + (size_t)g * CIN), f);
-        if (has1 || has2 || sw) {
+    for (int i = 0; i < C::NITA; ++i) {
+      const int e = tid + i * 256, r = e / C::CHA, c = e % C::CHA;
+      const int g = m0 * SA + offmin + r;
+      rawA[i] = make_uint4(0, 0, 0, 0);
+      if (r < C::RA && g >= 0 && g < a.Lin)
+        rawA[i] = *reinterpret_cast<const uint4*>(xb + (size_t)g * CIN + c * VEC);
+    }
+#pragma unroll
+    for (int i = 0; i < C::NITB; ++i) {
+      const int e = tid + i * 256, r = e / C::CHB, c = e % C::CHB;
+      const int g = m0 * U + r;
+      rawB[i] = make_uint4(0, 0, 0, 0);
+      if (r < C::RB && g < dyend) rawB[i] = *reinterpret_cast<const uint4*>(yb + (size_t)g * COUT + c * VEC);
+    }
+  };
+  auto put = [&](LT* base, int planes_stride, int pitch, int r, int c, const float* f) {
+    LT* dst = base + (size_t)r * pitch + c * VEC;
+    if constexpr (NPL == 2) {
+      uint2 hi, lo;
+      sa_split4(f, hi, lo);
+      *reinterpret_cast<uint2*>(dst) = hi;
+      *reinterpret_cast<uint2*>(dst + planes_stride) = lo;
+    } else {
+      *reinterpret_cast<uint4*>(dst) = tr::pack(f);
+    }
+  };
+  auto stage = [&](int m0) {
+#pragma unroll
+    for (int i = 0; i < C::NITA; ++i) {
+      const int e = tid + i * 256, r = e / C::CHA, c = e % C::CHA;
+      if (r < C::RA) {
+        const int g = m0 * SA + offmin + r;
+        float f[VEC];
+        tr::unpack(rawA[i], f);
+        if ((has1 || has2 || sw) && g >= 0 && g < a.Lin) {
 #pragma unroll
           for (int j = 0; j < VEC; ++j) {
             float v = f[j];
-            if (has1) v = fmaf(v, s1[j], t1[j]);
+            if (has1) v = fmaf(v, s1r[j], t1r[j]);
             if (sw) v = sa_swish(v);
-            if (has2) v = fmaf(v, s2[j], t2[j]);
+            if (has2) v = fmaf(v, s2r[j], t2r[j]);
             f[j] = v;
           }
         }
-      }
-      LT* dst = At + (size_t)r * PA + ca * VEC;
-      if constexpr (NPL == 2) {
-        uint2 hi, lo;
-        sa_split4(f, hi, lo);
-        *reinterpret_cast<uint2*>(dst) = hi;
-        *reinterpret_cast<uint2*>(dst + KT * PA) = lo;
-      } else {
-        *reinterpret_cast<uint4*>(dst) = tr::pack(f);
+        put(At, C::RA * PA, PA, r, c, f);
       }
     }
-    for (int r = rb0; r < KT; r += RPB) {
-      const int m = mt0 + r, g = m * U + ph;
-      uint4 u = make_uint4(0, 0, 0, 0);
-      if (m < mend && g < a.Ldy) u = *reinterpret_cast<const uint4*>(yb + (size_t)g * COUT);
-      LT* dst = Bt + (size_t)r * PB + cb * VEC;
-      if constexpr (NPL == 2) {
+#pragma unroll
+    for (int i = 0; i < C::NITB; ++i) {
+      const int e = tid + i * 256, r = e / C::CHB, c = e % C::CHB;
+      if (r < C::RB) {
         float f[VEC];
-        tr::unpack(u, f);
-        uint2 hi, lo;
-        sa_split4(f, hi, lo);
-        *reinterpret_cast<uint2*>(dst) = hi;
-        *reinterpret_cast<uint2*>(dst + KT * PB) = lo;
-      } else {
-        *reinterpret_cast<uint4*>(dst) = u;
+        tr::unpack(rawB[i], f);
+        put(Bt, C::RB * PB, PB, r, c, f);
       }
     }
+  };
+
+  const int g4 = lane >> 4, i16 = lane & 15;
+  const int trow = 8 * (g4 >> 1) + (i16 >> 2);             // tr-read: k within the 16-deep step
+  const int tcol = 16 * (g4 & 1) + 4 * (i16 & 3);          //          column within the 32-wide tile
+
+  issue(mbeg);
+  for (int m0 = mbeg; m0 < mend; m0 += KT) {
+    stage(m0);
     __syncthreads();
-    // ---- MFMA over the KT rows ----
-    const int g4 = lane >> 4, i16 = lane & 15;
-    const int troff = (8 * (g4 >> 1) + (i16 >> 2));       // tr-read: row within the k-step block
-    const int tcoff = 16 * (g4 & 1) + 4 * (i16 & 3);      //          column within the 32-wide tile
-#pragma unroll 2
-    for (int k0 = 0; k0 < KT; k0 += KS) {
-      Frag bfr[NPW], bfl[NPW];
+    if (m0 + KT < mend) issue(m0 + KT);
+    for (int ks = kw; ks < KT / KS; ks += C::KW) {
+      if constexpr (sizeof(LT) == 2) {
+        Frag bh[U], bl[U];
 #pragma unroll
-      for (int j = 0; j < NPW; ++j) {
-        const int nt = wn + j * WN;
-        if constexpr (sizeof(LT) == 2) {
-          const LT* p = Bt + (size_t)(k0 + troff) * PB + nt * 32 + tcoff;
-          bfr[j] = sa_tr_frag(p, PB);
-          if constexpr (NPL == 2) bfl[j] = sa_tr_frag(p + KT * PB, PB);
-        } else {
-          bfr[j] = Bt[(size_t)(k0 + (lane >> 5)) * PB + nt * 32 + (lane & 31)];
+        for (int ph = 0; ph < U; ++ph) {
+          const LT* p = Bt + (size_t)((ks * 16 + trow) * U + ph) * PB + nt * 32 + tcol;
+          bh[ph] = sa_tr_frag(p, U * PB);
+          if constexpr (NPL == 2) bl[ph] = sa_tr_frag(p + C::RB * PB, U * PB);
         }
-      }
 #pragma unroll
-      for (int i2 = 0; i2 < MPW; ++i2) {
-        const int mt = wm + i2 * WM;
-        if (mt < MT) {
-          if constexpr (sizeof(LT) == 2) {
-            const LT* p = At + (size_t)(k0 + troff) * PA + mt * 32 + tcoff;
-            const Frag af = sa_tr_frag(p, PA);
+        for (int t = 0; t < SA_MAX_TAPS; ++t) {
+          if (t < a.ntaps) {
+            const LT* p = At + (size_t)((ks * 16 + trow) * SA + a.off[t] - offmin) * PA + mt * 32 + tcol;
+            const Frag ah = sa_tr_frag(p, SA * PA);
+            const int ph = U == 1 ? 0 : a.ph[t];
             if constexpr (NPL == 2) {
-              const Frag al = sa_tr_frag(p + KT * PA, PA);
-#pragma unroll
-              for (int j = 0; j < NPW; ++j) {
-                acc[i2][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bfr[j], acc[i2][j], 0, 0, 0);
-                acc[i2][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, bfl[j], acc[i2][j], 0, 0, 0);
-                acc[i2][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, bfr[j], acc[i2][j], 0, 0, 0);
-              }
+              const Frag al = sa_tr_frag(p + C::RA * PA, SA * PA);
+              acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, ph ? bh[U - 1] : bh[0], acc[t], 0, 0, 0);
+              acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, ph ? bl[U - 1] : bl[0], acc[t], 0, 0, 0);
+              acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, ph ? bh[U - 1] : bh[0], acc[t], 0, 0, 0);
             } else {
-#pragma unroll
-              for (int j = 0; j < NPW; ++j)
-                acc[i2][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, bfr[j], acc[i2][j], 0, 0, 0);
+              acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, ph ? bh[U - 1] : bh[0], acc[t], 0, 0, 0);
             }
-          } else {
-            const Frag af = At[(size_t)(k0 + (lane >> 5)) * PA + mt * 32 + (lane & 31)];
+          }
+        }
+      } else {
+        float bv[U];
 #pragma unroll
-            for (int j = 0; j < NPW; ++j)
-              acc[i2][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af, bfr[j], acc[i2][j], 0, 0, 0);
+        for (int ph = 0; ph < U; ++ph)
+          bv[ph] = Bt[(size_t)((ks * 2 + (lane >> 5)) * U + ph) * PB + nt * 32 + (lane & 31)];
+#pragma unroll
+        for (int t = 0; t < SA_MAX_TAPS; ++t) {
+          if (t < a.ntaps) {
+            const float av = At[(size_t)((ks * 2 + (lane >> 5)) * SA + a.off[t] - offmin) * PA + mt * 32 + (lane & 31)];
+            const int ph = U == 1 ? 0 : a.ph[t];
+            acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, ph ? bv[U - 1] : bv[0], acc[t], 0, 0, 0);
           }
         }
       }
@@ -248,26 +285,35 @@ __global__ __launch_bounds__(256) void sa_wgrad_kernel(SaWgradArgs a) {
     __syncthreads();
   }
 
-  // ---- write the fp32 partial slab [CIN][COUT] ----
-  float* slab = a.slabs + ((((size_t)b * a.nchunk + chunk) * a.ntaps + tap) * CIN) * COUT;
+  // ---- fp32 partial slab [kw][tap][CIN][COUT]; this workgroup writes its MS x NS sub-block ----
+  float* slab = a.slabs + ((((size_t)b * a.nchunk + chunk) * C::KW + kw) * a.ntaps) * CIN * COUT;
 #pragma unroll
-  for (int i2 = 0; i2 < MPW; ++i2) {
-    const int mt = wm + i2 * WM;
-    if (mt < MT) {
+  for (int t = 0; t < SA_MAX_TAPS; ++t) {
+    if (t < a.ntaps) {
 #pragma unroll
-      for (int j = 0; j < NPW; ++j) {
-        const int nt = wn + j * WN;
-#pragma unroll
-        for (int r = 0; r < 16; ++r)
-          slab[(size_t)(mt * 32 + sa_acc_row(r, lane)) * COUT + nt * 32 + (lane & 31)] = acc[i2][j][r];
-      }
+      for (int r = 0; r < 16; ++r)
+        slab[((size_t)t * CIN + cm0 + mt * 32 + sa_acc_row(r, lane)) * COUT + cn0 + nt * 32 + (lane & 31)] = acc[t][r];
     }
   }
 }
 
+// slabs per (utterance, chunk): the k-step split factor of the configuration
+extern "C" int sa_wgrad_kw(int cin, int cout) {
+  const int ms = cin < 64 ? cin : 64, ns = cout < 64 ? cout : 64;
+  return 4 / ((ms / 32) * (ns / 32));
+}
+
 template <typename T, int CIN, int COUT, int SA, int U>
 static int launch_wgrad(const SaWgradArgs& a, hipStream_t st) {
-  dim3 grid(a.nchunk, a.ntaps, a.B);
+  typedef WgCfg<T, CIN, COUT, SA, U> C;
+  int omin = a.off[0], omax = a.off[0];
+  for (int t = 1; t < a.ntaps; ++t) {
+    omin = a.off[t] < omin ? a.off[t] : omin;
+    omax = a.off[t] > omax ? a.off[t] : omax;
+  }
+  if (omax - omin > C::HALO) return -22;
+  for (int t = 0; t < a.ntaps; ++t) if (a.ph[t] < 0 || a.ph[t] >= U) return -22;
+  dim3 grid(a.nchunk, (CIN / C::MS) * (COUT / C::NS), a.B);
   hipLaunchKernelGGL((sa_wgrad_kernel<T, CIN, COUT, SA, U>), grid, dim3(256), 0, st, a);
   hipError_t e = hipGetLastError();
   return e == hipSuccess ? 0 : -(int)e;
@@ -297,16 +343,28 @@ extern "C" int sa_wgrad(int dtype, int cin, int cout, int sa, int u, const SaWgr
 // ---------------------------------------------------------------------------------
 // sa_wgrad_reduce: dst[ci*sk + co*sn + t*st] (=|+=) sum over nslab slabs [t][ci][co]
 // ---------------------------------------------------------------------------------
-__global__ void sa_wgrad_reduce_kernel(const float* __restrict__ slabs, float* __restrict__ dst,
-                                       int nslab, int ntaps, int CIN, int COUT, int sk, int sn,
-                                       int st, int accumulate) {
+// 256 threads = 16 outputs x 16 slab lanes (fixed summation order -> deterministic)
+__global__ __launch_bounds__(256) void sa_wgrad_reduce_kernel(const float* __restrict__ slabs,
+                                                              float* __restrict__ dst, int nslab,
+                                                              int ntaps, int CIN, int COUT, int sk,
+                                                              int sn, int st, int accumulate) {
+  __shared__ double part[16][17];
   const int per = ntaps * CIN * COUT;
-  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < per; i += gridDim.x * blockDim.x) {
-    double s = 0.0;
-    for (int k = 0; k < nslab; ++k) s += (double)slabs[(size_t)k * per + i];
-    const int co = i % COUT, ci = (i / COUT) % CIN, t = i / (COUT * CIN);
-    const size_t d = (size_t)ci * sk + (size_t)co * sn + (size_t)t * st;
-    dst[d] = accumulate ? dst[d] + (float)s : (float)s;
+  const int o = threadIdx.x & 15, q = threadIdx.x >> 4, i = blockIdx.x * 16 + o;
+  double s = 0.0;
+  if (i < per) {
+#pragma unroll 4
+    for (int k = q; k < nslab; k += 16) s += (double)slabs[(size_t)k * per + i];
+  }
+  part[q][o] = s;
+  __syncthreads();
+  if (q == 0 && i < per) {
+    double t = 0.0;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) t += part[r][o];
+    const int co = i % COUT, ci = (i / COUT) % CIN, tp = i / (COUT * CIN);
+    const size_t d = (size_t)ci * sk + (size_t)co * sn + (size_t)tp * st;
+    dst[d] = accumulate ? dst[d] + (float)t : (float)t;
   }
 }
 
@@ -314,7 +372,7 @@ extern "C" int sa_wgrad_reduce(const float* slabs, float* dst, int nslab, int nt
                                int cout, int sk, int sn, int st, int accumulate, void* stream) {
   if (!slabs || !dst || nslab <= 0) return -22;
   const int per = ntaps * cin * cout;
-  hipLaunchKernelGGL(sa_wgrad_reduce_kernel, dim3(sa_div_up(per, 256)), dim3(256), 0,
+  hipLaunchKernelGGL(sa_wgrad_reduce_kernel, dim3(sa_div_up(per, 16)), dim3(256), 0,
                      reinterpret_cast<hipStream_t>(stream), slabs, dst, nslab, ntaps, cin, cout,
                      sk, sn, st, accumulate);
   hipError_t e = hipGetLastError();

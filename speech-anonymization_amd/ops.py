@@ -109,7 +109,7 @@ def conv_gemm(x, wp, bias, cin, cout, sa, u, phases, Lout, s1=None, t1=None, s2=
     B, Lin, _ = x.shape
     assert x.shape[2] == cin
     y = out if out is not None else torch.empty(B, Lout, cout, dtype=x.dtype, device=x.device)
-    nt = lib.sa_conv_gemm_ntiles(Lout, u)
+    nt = lib.sa_conv_gemm_ntiles(cin, cout, u, Lout)
     stats = torch.empty(B, nt, cout, 2, dtype=torch.float32, device=x.device) if want_stats else None
     a = L.SaConvArgs()
     a.x, a.wp, a.bias, a.y = _f(x), _f(wp), _f(bias), _f(y)
@@ -130,17 +130,19 @@ def conv_gemm(x, wp, bias, cin, cout, sa, u, phases, Lout, s1=None, t1=None, s2=
 
 
 def wgrad(x, dy, cin, cout, sa, u, taps, Mrows, dst, dst_strides, s1=None, t1=None, s2=None,
-          t2=None, swish=False, accumulate=False, target_wgs=768, code=None):
+          t2=None, swish=False, accumulate=False, target_wgs=640, code=None):
     """taps: list of (row_offset, phase) per weight tap.  dst: fp32 parameter-gradient tensor in
     PyTorch layout; dst_strides = (s_ci, s_co, s_tap)."""
     lib = L.load()
     B, Lin, _ = x.shape
     Ldy = dy.shape[1]
     nt = len(taps)
-    chunk = max(64, -(-Mrows * nt * B // target_wgs))
+    kw = lib.sa_wgrad_kw(cin, cout)
+    nsub = (cin // min(cin, 64)) * (cout // min(cout, 64))
+    chunk = max(64, -(-Mrows * nsub * B // target_wgs))
     chunk = -(-chunk // 64) * 64
     nchunk = -(-Mrows // chunk)
-    slabs = torch.empty(B * nchunk * nt * cin * cout, dtype=torch.float32, device=x.device)
+    slabs = torch.empty(B * nchunk * kw * nt * cin * cout, dtype=torch.float32, device=x.device)
     a = L.SaWgradArgs()
     a.x, a.dy, a.slabs = _f(x), _f(dy), _f(slabs)
     a.s1, a.t1, a.s2, a.t2, a.swish = _f(s1), _f(t1), _f(s2), _f(t2), int(swish)
@@ -151,7 +153,7 @@ def wgrad(x, dy, cin, cout, sa, u, taps, Mrows, dst, dst_strides, s1=None, t1=No
                          C.byref(a), L.stream()),
             f"sa_wgrad({cin},{cout},{sa},{u})")
     sk, sn, st = dst_strides
-    L.check(lib.sa_wgrad_reduce(_f(slabs), _f(dst), B * nchunk, nt, cin, cout, sk, sn, st,
+    L.check(lib.sa_wgrad_reduce(_f(slabs), _f(dst), B * nchunk * kw, nt, cin, cout, sk, sn, st,
                                 int(accumulate), L.stream()), "sa_wgrad_reduce")
     return dst
 
