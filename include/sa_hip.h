@@ -175,6 +175,7 @@ int sa_cluster_mi(const float* X, const long long* y, const long long* idx, int 
 int sa_fbank(const float* wav, int B, int N, const float* window, const float* dft,
              const float* mel, float* feats, float* tilemax, void* stream);
 int sa_fbank_ntiles(int T);
+int sa_fbank_scratch_bytes(int B);
 int sa_fbank_normalize(const float* feats, const float* tilemax, int B, int T, int Tp,
                        const float* lens, float top_db, int batch_max, int update, int epoch,
                        int update_until_epoch, float* state, float* scratch, float* out,

@@ -92,6 +92,7 @@ class Brain:
         self.device = torch.device(run_opts.get("device", "cuda:0" if torch.cuda.is_available() else "cpu"))
         self.max_grad_norm = float(run_opts.get("max_grad_norm", 5.0))
         self.nonfinite_patience = int(run_opts.get("nonfinite_patience", 3))
+        self.lazy_finite_check = bool(run_opts.get("lazy_finite_check", True))
         self.distributed_launch = bool(run_opts.get("distributed_launch", sdist.is_distributed()))
         self.modules = torch.nn.ModuleDict(modules or {})
         self.opt_class = opt_class
@@ -124,13 +125,24 @@ class Brain:
     def check_gradients(self, loss):
         """speechbrain semantics: count non-finite losses (raise after `nonfinite_patience`),
         otherwise clip the global gradient norm to max_grad_norm."""
-        if not torch.isfinite(loss):
+        finite = self._finite_check(loss)
+        if not finite:
             self.nonfinite_count += 1
             if self.nonfinite_count > self.nonfinite_patience:
                 raise ValueError("Loss is not finite and patience is exhausted.")
             return False
         torch.nn.utils.clip_grad_norm_((p for p in self.modules.parameters()), self.max_grad_norm)
         return True
+
+    def _finite_check(self, loss):
+        """`torch.isfinite(loss)` read on the host would stall the CPU until the GPU has finished
+        the whole backward of this step, every step.  With lazy_finite_check (run_opts, default
+        True on GPU) the flag of the PREVIOUS step is read instead (already complete), so a
+        non-finite loss is counted one step late; False restores the synchronous check."""
+        if not (self.lazy_finite_check and loss.is_cuda):
+            return bool(torch.isfinite(loss))
+        prev, self._pending_finite = getattr(self, "_pending_finite", None), torch.isfinite(loss.detach())
+        return True if prev is None else bool(prev)
 
     def fit_batch(self, batch):
         outputs = self.compute_forward(batch, Stage.TRAIN)

@@ -119,19 +119,19 @@ extern "C" int sa_fbank(const float* wav, int B, int N, const float* window, con
 }
 
 // Per-utterance statistics of the top-dB-clamped features over the first round(len*T) frames:
-// floor[b] = max - top_db (per utterance, or the batch max when batch_max != 0),
-// umean/ustd [B][80] (unbiased std, floored at 1e-10).  One workgroup per utterance.
-__global__ __launch_bounds__(256) void sa_fbank_utt_stats_kernel(const float* __restrict__ feats,
-                                                                 const float* __restrict__ tilemax,
-                                                                 int ntiles, int B, int T,
-                                                                 const float* __restrict__ lens,
-                                                                 float top_db, int batch_max,
-                                                                 float* __restrict__ floor_out,
-                                                                 float* __restrict__ umean,
-                                                                 float* __restrict__ ustd) {
+// floor[b] = max - top_db (per utterance, or the batch max when batch_max != 0), and partial
+// (sum, sumsq) per Mel bin for SA_UTT_CHUNKS frame chunks of each utterance (fp64).
+#define SA_UTT_CHUNKS 16
+__global__ __launch_bounds__(256) void sa_fbank_utt_partial_kernel(const float* __restrict__ feats,
+                                                                   const float* __restrict__ tilemax,
+                                                                   int ntiles, int B, int T,
+                                                                   const float* __restrict__ lens,
+                                                                   float top_db, int batch_max,
+                                                                   float* __restrict__ floor_out,
+                                                                   double* __restrict__ part) {
   __shared__ float smax[256];
   __shared__ double acc[3][SA_NMEL][2];
-  const int tid = threadIdx.x, b = blockIdx.x;
+  const int tid = threadIdx.x, ch = blockIdx.x, b = blockIdx.y;
   float mx = -INFINITY;
   if (batch_max) { for (int i = tid; i < B * ntiles; i += 256) mx = fmaxf(mx, tilemax[i]); }
   else { for (int i = tid; i < ntiles; i += 256) mx = fmaxf(mx, tilemax[(size_t)b * ntiles + i]); }
@@ -139,13 +139,16 @@ __global__ __launch_bounds__(256) void sa_fbank_utt_stats_kernel(const float* __
   __syncthreads();
   for (int s = 128; s > 0; s >>= 1) { if (tid < s) smax[tid] = fmaxf(smax[tid], smax[tid + s]); __syncthreads(); }
   const float fl = smax[0] - top_db;
-  if (tid == 0) floor_out[b] = fl;
+  if (tid == 0 && ch == 0) floor_out[b] = fl;
   int n = (int)rintf(lens[b] * (float)T);
   if (n > T) n = T;
+  const int per = (T + SA_UTT_CHUNKS - 1) / SA_UTT_CHUNKS;
+  const int t0 = ch * per;
+  int t1 = t0 + per; if (t1 > n) t1 = n;
   if (tid < 240) {
     const int f = tid % SA_NMEL, p = tid / SA_NMEL;
     double s = 0.0, q = 0.0;
-    for (int t = p; t < n; t += 3) {
+    for (int t = t0 + p; t < t1; t += 3) {
       const float v = fmaxf(feats[((size_t)b * T + t) * SA_NMEL + f], fl);
       s += v; q += (double)v * v;
     }
@@ -153,26 +156,36 @@ __global__ __launch_bounds__(256) void sa_fbank_utt_stats_kernel(const float* __
   }
   __syncthreads();
   if (tid < SA_NMEL) {
-    const double s = acc[0][tid][0] + acc[1][tid][0] + acc[2][tid][0];
-    const double q = acc[0][tid][1] + acc[1][tid][1] + acc[2][tid][1];
-    const double m = s / n;
-    double var = n > 1 ? (q - s * m) / (n - 1) : 0.0;
-    if (var < 0.0) var = 0.0;
-    umean[b * SA_NMEL + tid] = (float)m;
-    ustd[b * SA_NMEL + tid] = fmaxf((float)sqrt(var), 1e-10f);
+    double* d = part + (((size_t)b * SA_UTT_CHUNKS + ch) * SA_NMEL + tid) * 2;
+    d[0] = acc[0][tid][0] + acc[1][tid][0] + acc[2][tid][0];
+    d[1] = acc[0][tid][1] + acc[1][tid][1] + acc[2][tid][1];
   }
 }
 
-// InputNormalization "global" state update (speechbrain semantics restated in
-// oracle/features.py): state = [count, glob_mean[80], glob_std[80]] fp32 on device.
-__global__ void sa_norm_update_kernel(const float* __restrict__ umean, const float* __restrict__ ustd,
-                                      int B, int update, int epoch, int update_until_epoch,
+// InputNormalization "global": per-utterance mean / unbiased std (floored at 1e-10) from the
+// chunk partials, averaged over the batch, folded into the running state
+// [count, glob_mean[80], glob_std[80]] (speechbrain semantics restated in oracle/features.py).
+__global__ void sa_norm_update_kernel(const double* __restrict__ part, const float* __restrict__ lens,
+                                      int B, int T, int update, int epoch, int update_until_epoch,
                                       float* state) {
   const int f = threadIdx.x;
   const float count = state[0];
-  float cm = 0.f, cs = 0.f;
   if (f < SA_NMEL) {
-    for (int b = 0; b < B; ++b) { cm += umean[b * SA_NMEL + f]; cs += ustd[b * SA_NMEL + f]; }
+    float cm = 0.f, cs = 0.f;
+    for (int b = 0; b < B; ++b) {
+      int n = (int)rintf(lens[b] * (float)T);
+      if (n > T) n = T;
+      double s = 0.0, q = 0.0;
+      for (int c = 0; c < SA_UTT_CHUNKS; ++c) {
+        const double* d = part + (((size_t)b * SA_UTT_CHUNKS + c) * SA_NMEL + f) * 2;
+        s += d[0]; q += d[1];
+      }
+      const double m = s / n;
+      double var = n > 1 ? (q - s * m) / (n - 1) : 0.0;
+      if (var < 0.0) var = 0.0;
+      cm += (float)m;
+      cs += fmaxf((float)sqrt(var), 1e-10f);
+    }
     cm /= B; cs /= B;
     if (update) {
       if (count == 0.0f) { state[1 + f] = cm; state[1 + SA_NMEL + f] = cs; }
@@ -209,7 +222,11 @@ __global__ void sa_norm_apply_kernel(const float* __restrict__ feats, const floa
 }
 
 // feats [B][T][80] raw dB + tilemax -> out [B][Tp][80] normalised (+ zero pad rows);
-// scratch: floor[B], umean[B][80], ustd[B][80] (fp32, caller-allocated: B*(1+160) floats)
+// scratch: caller-allocated, sa_fbank_scratch_bytes(B) bytes (floor[B] + fp64 chunk partials)
+extern "C" int sa_fbank_scratch_bytes(int B) {
+  return (int)(((B + 1) & ~1) * sizeof(float) + (size_t)B * SA_UTT_CHUNKS * SA_NMEL * 2 * sizeof(double));
+}
+
 extern "C" int sa_fbank_normalize(const float* feats, const float* tilemax, int B, int T, int Tp,
                                   const float* lens, float top_db, int batch_max, int update,
                                   int epoch, int update_until_epoch, float* state, float* scratch,
@@ -217,10 +234,11 @@ extern "C" int sa_fbank_normalize(const float* feats, const float* tilemax, int 
   if (!feats || !tilemax || !lens || !state || !scratch || !out || B <= 0 || T <= 0 || Tp < T)
     return -22;
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-  float* fl = scratch; float* um = scratch + B; float* us = um + (size_t)B * SA_NMEL;
-  hipLaunchKernelGGL(sa_fbank_utt_stats_kernel, dim3(B), dim3(256), 0, st, feats, tilemax,
-                     sa_div_up(T, SA_FB_FRAMES), B, T, lens, top_db, batch_max, fl, um, us);
-  hipLaunchKernelGGL(sa_norm_update_kernel, dim3(1), dim3(128), 0, st, um, us, B, update, epoch,
+  float* fl = scratch;
+  double* part = reinterpret_cast<double*>(scratch + ((B + 1) & ~1));
+  hipLaunchKernelGGL(sa_fbank_utt_partial_kernel, dim3(SA_UTT_CHUNKS, B), dim3(256), 0, st, feats,
+                     tilemax, sa_div_up(T, SA_FB_FRAMES), B, T, lens, top_db, batch_max, fl, part);
+  hipLaunchKernelGGL(sa_norm_update_kernel, dim3(1), dim3(128), 0, st, part, lens, B, T, update, epoch,
                      update_until_epoch, state);
   const size_t n4 = (size_t)Tp * SA_NMEL / 4;
   hipLaunchKernelGGL(sa_norm_apply_kernel, dim3((unsigned)((n4 + 255) / 256), B), dim3(256), 0, st,

@@ -150,7 +150,7 @@ class InputNormalization(torch.nn.Module):
         Tp = T if not m or T % m == 0 else T + (m - T % m)
         lens = lengths.to(device=raw.device, dtype=torch.float32).contiguous()
         out = torch.empty(B, Tp, 80, dtype=torch.float32, device=raw.device)
-        scratch = torch.empty(B * 161, dtype=torch.float32, device=raw.device)
+        scratch = torch.empty(lib.sa_fbank_scratch_bytes(B) // 4, dtype=torch.float32, device=raw.device)
         L.check(lib.sa_fbank_normalize(L.ptr(raw), L.ptr(tmax), B, T, Tp, L.ptr(lens),
                                        C.c_float(top_db), int(bmax), int(self.training), int(epoch),
                                        int(self.update_until_epoch), L.ptr(self.state),

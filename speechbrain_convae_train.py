@@ -1,0 +1,71 @@
+#!/usr/bin/env python3
+"""Entry point with the reference's command line (speechbrain_convae_train.py:1-8,514-615):
+
+    python speechbrain_convae_train.py speechbrain_configs/convae.yaml \
+        --device cuda:0 --model_type convae --folder <output_dir> [--key value overrides]
+
+    # data-parallel on one node (one process per GPU, RCCL):
+    python -m torch.distributed.run --nproc-per-node 8 --master-addr 127.0.0.1 \
+        speechbrain_convae_train.py speechbrain_configs/convae.yaml --distributed_launch
+
+Extra options of this build: ``--synthetic N`` trains on N synthetic utterances per epoch instead
+of CSV manifests (there is no dataset on the GPU box).  The frozen-ASR utility loss, the external
+x-vector evaluation and WER are not part of this path."""
+import os
+import sys
+
+import torch
+
+import speech_anonymization_amd as pkg
+from speech_anonymization_amd import brain as B, convae, data, distributed as sdist
+from speech_anonymization_amd.yaml_loader import load_hyperpyyaml, parse_arguments
+
+
+def main(argv):
+    hparams_file, run_opts, overrides = parse_arguments(argv)
+    synthetic = overrides.pop("synthetic", None)
+    n_samples = int(overrides.pop("synthetic_samples", 161120))
+    with open(hparams_file) as fin:
+        hparams = load_hyperpyyaml(fin, overrides)
+    rank, local_rank, world = sdist.ddp_init_group(run_opts)
+    run_opts.setdefault("device", f"cuda:{local_rank}")
+    if sdist.if_main_process():
+        os.makedirs(hparams["output_folder"], exist_ok=True)
+
+    if hparams["model_type"] != "convae":
+        raise SystemExit("this path implements model_type convae (SURVEY.md 8)")
+    model = convae.ConvAutoencoder(precision=hparams.get("precision", "bf16x3"))
+
+    sa_brain = B.SexAnonymizationTraining(modules=hparams["modules"], opt_class=hparams["Adam"],
+                                          hparams=hparams, run_opts=run_opts,
+                                          checkpointer=hparams.get("checkpointer"))
+    model = model.to(sa_brain.device)
+    sa_brain.modules["ConvAE"] = model
+    hparams["model"].append(sa_brain.modules["ConvAE"])      # ModuleList index 0 (reference :580)
+
+    bs = hparams["batch_size"]
+    if synthetic:
+        train = lambda: data.synthetic_dataset(int(synthetic), bs, n_samples, rank=rank, world=world)
+        valid = lambda: data.synthetic_dataset(bs * world, bs, n_samples, seed=1, rank=rank, world=world)
+    else:
+        rep = {"data_root": hparams["data_folder"]}
+        tr = data.CsvDataset(hparams["train_csv"], rep, hparams.get("sorting", "random"))
+        va = data.CsvDataset(hparams["valid_csv"], rep, "ascending")
+        shuffle = hparams["train_dataloader_opts"].get("shuffle", False) and hparams.get("sorting") == "random"
+        train = lambda: data.batches(tr, bs, shuffle, hparams["seed"], rank, world)
+        valid = lambda: data.batches(va, bs, False, 0, rank, world)
+
+    class Loader:
+        def __init__(self, f):
+            self.f = f
+
+        def __iter__(self):
+            return iter(self.f())
+
+    sa_brain.fit(hparams["epoch_counter"], Loader(train), Loader(valid))
+    if sdist.world_size() > 1:
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main(sys.argv[1:])

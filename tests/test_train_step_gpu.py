@@ -42,3 +42,27 @@ def test_frozen_classifier_and_recon_only():
             assert p.grad is None, name
         else:
             assert p.grad is not None and torch.isfinite(p.grad).all(), name
+
+
+def test_entry_script_config1_plumbing(tmp_path):
+    """BASELINE config 1 on the GPU path: speechbrain_convae_train.py + convae.yaml, recon 1.0 only
+    (MSE), gradient accumulation 3, synthetic utterances; writes train_log.txt and a checkpoint
+    directory with the reference's layout."""
+    import os
+    import speechbrain_convae_train as entry
+    cfg = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))),
+                       "speechbrain_configs", "convae.yaml")
+    entry.main([cfg, "--device", "cuda:0", "--model_type", "convae", "--folder", str(tmp_path),
+                "--number_of_epochs", "2", "--batch_size", "2", "--synthetic", "12",
+                "--synthetic_samples", "11360"])
+    out = tmp_path / "8886"
+    lines = open(out / "train_log.txt").read().strip().splitlines()
+    assert len(lines) == 2 and lines[0].startswith("epoch: 1, lr: ") and "train loss" in lines[0]
+    assert "steps: 2" in lines[0]                       # 6 batches / gradient_accumulation 3
+    l1 = float(lines[0].split("train loss: ")[1].split(" ")[0])
+    l2 = float(lines[1].split("train loss: ")[1].split(" ")[0])
+    assert l2 < l1                                      # recon-only MSE goes down
+    ck = sorted(os.listdir(out / "save"))
+    assert ck and ck[-1].startswith("CKPT+")
+    assert {"model.ckpt", "normalizer.ckpt", "noam_scheduler.ckpt", "counter.ckpt", "CKPT.yaml"} <= set(
+        os.listdir(out / "save" / ck[-1]))
