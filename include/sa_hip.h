@@ -165,6 +165,16 @@ int sa_cls_losses(const float* logp, const long long* label, int B, int NC, floa
 int sa_cosine_loss(const float* x1, const float* x2, int B, int S, int D, float* rowloss,
                    float* loss, float* dx1, void* stream);
 
+/* x-vector gender classifier forward (models/external_gender_classifiers.py:71-115,144-183;
+ * evaluator_inference.yaml:34-48): TDNN block = speechbrain Conv1d (reflect "same" padding) ->
+ * LeakyReLU -> BatchNorm1d(eval); StatisticsPooling over time with relative lengths. */
+int sa_tdnn_fwd(const float* x, const float* w, const float* bias, const float* bn_s, const float* bn_t,
+                float* y, int B, int T, int Cin, int Cout, int K, int dil, float slope, void* stream);
+int sa_time_pool(const float* x, const float* lens, const float* noise, int B, int T, int C, float eps,
+                 float* out, void* stream);
+int sa_leaky_affine(const float* x, const float* s, const float* t, float slope, int M, int C, float* y,
+                    void* stream);
+
 /* ---- k-NN mutual information (sa_mi.hip): utils/ClusterMI.py:88-121,
  * utils/GroupSamplingMI.py:49-61, utils/mi_loss.py:14-17 ------------------------------ */
 int sa_cluster_mi(const float* X, const long long* y, const long long* idx, int iters, int n, int D,

@@ -469,3 +469,119 @@ extern "C" int sa_cosine_loss(const float* x1, const float* x2, int B, int S, in
   hipError_t e = hipGetLastError();
   return e == hipSuccess ? 0 : -(int)e;
 }
+
+// ---------------------------------------------------------------------------------
+// x-vector TDNN layer (forward, eval): speechbrain Conv1d ("same" reflect padding, dilation)
+// -> LeakyReLU -> BatchNorm1d(eval), the block of models/external_gender_classifiers.py:71-87
+// (Xvector, used through evaluator_inference.yaml:34-41).  Activations are [B][T][C] already.
+//   y[b][t][co] = bn_s[co] * leaky( bias[co] + sum_{k,ci} x[b][refl(t + k*dil - pad)][ci] * w[co][ci][k] ) + bn_t[co]
+// Exact-f32 MFMA, one wave per 32x32 output tile; this is an evaluation-only path (not in the
+// train step), written for correctness first.
+// ---------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void sa_tdnn_fwd_kernel(const float* __restrict__ x,
+                                                         const float* __restrict__ w,
+                                                         const float* __restrict__ bias,
+                                                         const float* __restrict__ bn_s,
+                                                         const float* __restrict__ bn_t,
+                                                         float* __restrict__ y, int B, int T, int Cin,
+                                                         int Cout, int K, int dil, float slope) {
+  const int lane = threadIdx.x, n0 = blockIdx.x * 32, m0 = blockIdx.y * 32;
+  const int M = B * T;
+  const int m = m0 + (lane & 31), n = n0 + (lane & 31), kh = lane >> 5;
+  const int pad = dil * (K - 1) / 2;
+  const int b = m < M ? m / T : 0, t = m < M ? m % T : 0;
+  f32x16 acc;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) acc[i] = 0.0f;
+  for (int k = 0; k < K; ++k) {
+    int tt = t + k * dil - pad;
+    if (tt < 0) tt = -tt;                                   // reflect (no edge repeat)
+    if (tt >= T) tt = 2 * (T - 1) - tt;
+    const float* xr = x + ((size_t)b * T + tt) * Cin;
+    for (int c0 = 0; c0 < Cin; c0 += 2) {
+      const int ci = c0 + kh;
+      float av = 0.0f, bv = 0.0f;
+      if (ci < Cin) {
+        if (m < M) av = xr[ci];
+        if (n < Cout) bv = w[((size_t)n * Cin + ci) * K + k];
+      }
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc, 0, 0, 0);
+    }
+  }
+  if (n < Cout) {
+    const float bb = bias ? bias[n] : 0.0f, s = bn_s ? bn_s[n] : 1.0f, sh = bn_t ? bn_t[n] : 0.0f;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const int mr = m0 + sa_acc_row(i, lane);
+      if (mr < M) {
+        float v = acc[i] + bb;
+        v = v > 0.0f ? v : v * slope;
+        y[(size_t)mr * Cout + n] = fmaf(v, s, sh);
+      }
+    }
+  }
+}
+
+extern "C" int sa_tdnn_fwd(const float* x, const float* w, const float* bias, const float* bn_s,
+                           const float* bn_t, float* y, int B, int T, int Cin, int Cout, int K,
+                           int dil, float slope, void* stream) {
+  if (!x || !w || !y || B <= 0 || T <= 0 || Cin <= 0 || Cout <= 0 || K < 1 || !(K & 1) || dil < 1 ||
+      dil * (K - 1) / 2 >= T)
+    return -22;
+  dim3 grid(sa_div_up(Cout, 32), sa_div_up(B * T, 32));
+  hipLaunchKernelGGL(sa_tdnn_fwd_kernel, grid, dim3(64), 0, reinterpret_cast<hipStream_t>(stream), x, w,
+                     bias, bn_s, bn_t, y, B, T, Cin, Cout, K, dil, slope);
+  hipError_t e = hipGetLastError();
+  return e == hipSuccess ? 0 : -(int)e;
+}
+
+// speechbrain StatisticsPooling over time with relative lengths: mean and unbiased std (+eps) of
+// the first round(len*T) frames per (utterance, channel); out [B][2C] = (mean (+noise), std).
+__global__ void sa_time_pool_kernel(const float* __restrict__ x, const float* __restrict__ lens,
+                                    const float* __restrict__ noise, int T, int C, float eps,
+                                    float* __restrict__ out) {
+  const int b = blockIdx.y, c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  int n = lens ? (int)rintf(lens[b] * (float)T) : T;
+  if (n > T) n = T;
+  double s = 0.0, q = 0.0;
+  for (int t = 0; t < n; ++t) {
+    const double v = x[((size_t)b * T + t) * C + c];
+    s += v; q += v * v;
+  }
+  const double m = s / n;
+  double var = n > 1 ? (q - s * m) / (n - 1) : 0.0;
+  if (var < 0.0) var = 0.0;
+  float mo = (float)m;
+  if (noise) mo += eps * ((1.0f - 9.0f) * noise[(size_t)b * C + c] + 9.0f);
+  out[(size_t)b * 2 * C + c] = mo;
+  out[(size_t)b * 2 * C + C + c] = (float)sqrt(var) + eps;
+}
+
+extern "C" int sa_time_pool(const float* x, const float* lens, const float* noise, int B, int T, int C,
+                            float eps, float* out, void* stream) {
+  if (!x || !out || B <= 0 || T <= 0 || C <= 0) return -22;
+  hipLaunchKernelGGL(sa_time_pool_kernel, dim3(sa_div_up(C, 128), B), dim3(128), 0,
+                     reinterpret_cast<hipStream_t>(stream), x, lens, noise, T, C, eps, out);
+  hipError_t e = hipGetLastError();
+  return e == hipSuccess ? 0 : -(int)e;
+}
+
+// y = x > 0 ? x : slope*x, then *s[c] + t[c]  (LeakyReLU -> BatchNorm(eval) on a small [M][C])
+__global__ void sa_leaky_affine_kernel(const float* __restrict__ x, const float* __restrict__ s,
+                                       const float* __restrict__ t, float slope, int M, int C, float* y) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= M * C) return;
+  float v = x[i];
+  v = v > 0.0f ? v : v * slope;
+  y[i] = s ? fmaf(v, s[i % C], t[i % C]) : v;
+}
+
+extern "C" int sa_leaky_affine(const float* x, const float* s, const float* t, float slope, int M, int C,
+                               float* y, void* stream) {
+  if (!x || !y) return -22;
+  hipLaunchKernelGGL(sa_leaky_affine_kernel, dim3(sa_div_up(M * C, 256)), dim3(256), 0,
+                     reinterpret_cast<hipStream_t>(stream), x, s, t, slope, M, C, y);
+  hipError_t e = hipGetLastError();
+  return e == hipSuccess ? 0 : -(int)e;
+}

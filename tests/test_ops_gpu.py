@@ -403,3 +403,38 @@ def test_fbank_and_normalization(mode):
     assert sd["count"] == onorm.count
     assert torch.allclose(sd["glob_mean"].cpu(), onorm.glob_mean, atol=1e-3)
     assert torch.allclose(sd["glob_std"].cpu(), onorm.glob_std, atol=1e-3)
+
+
+def test_xvector_classifier_forward():
+    """x-vector gender classifier forward (eval) vs the oracle restatement, with the
+    reference checkpoint's parameter naming."""
+    import json, os
+    from oracle import xvector as OX
+    from speech_anonymization_amd import xvector as HX
+    torch.manual_seed(3)
+    ox, oc = OX.Xvector().eval(), OX.Classifier().eval()
+    for m in list(ox.modules()) + list(oc.modules()):
+        if isinstance(m, torch.nn.BatchNorm1d):                 # non-trivial running statistics
+            m.running_mean.normal_(0, 0.3); m.running_var.uniform_(0.5, 1.5)
+            m.weight.data.uniform_(0.8, 1.2); m.bias.data.normal_(0, 0.1)
+    hx, hc = HX.Xvector(pooling_noise=None), HX.Classifier(input_shape=[None, None, 128])
+    assert list(hx.state_dict().keys()) == list(ox.state_dict().keys())
+    assert list(hc.state_dict().keys()) == list(oc.state_dict().keys())
+    pins = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "reference_pins.json")))
+    assert {k: list(v.shape) for k, v in hc.state_dict().items()} == pins["classifier_ckpt"]["shapes"]
+    hx.load_state_dict(ox.state_dict()); hc.load_state_dict(oc.state_dict())
+    hx.to(dev()); hc.to(dev())
+    B, T = 3, 90
+    feats = rnd(torch.float32, B, T, 80, seed=61)
+    lens = torch.tensor([1.0, 0.77, 0.5])
+    with torch.no_grad():
+        e_ref = ox(feats, lens)
+        p_ref = oc(e_ref)
+    e = hx(feats.to(dev()), lens)
+    p = hc(e)
+    torch.cuda.synchronize()
+    assert e.shape == (B, 1, 128) and p.shape == (B, 1, 2)
+    assert rel_mse(e, e_ref) < 1e-9 and rel_mse(p, p_ref) < 1e-9
+    enc = HX.EncoderClassifier(hx, hc)
+    out, score, index = enc.classify_batch_feats(feats.to(dev()), lens)
+    assert out.shape == (B, 2) and index.shape == (B,)
