@@ -93,7 +93,8 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--batch", type=int, default=10, help="utterances per GPU (shape M: 10)")
+    ap.add_argument("--batch", type=int, default=32,
+                    help="utterances per GPU of shape M (BASELINE.md config 2: B 10 and B 32)")
     ap.add_argument("--dtype", default=os.environ.get("SA_BENCH_DTYPE", "bf16x3"),
                     choices=["bf16x3", "bf16", "f32"],
                     help="bf16x3 (default): fp32 storage + split-bf16 operands on the bf16 MFMA, "
@@ -151,6 +152,15 @@ def main():
                         "peak": MFMA_PEAK_TFLOPS[args.dtype], "unit": "TFLOP/s"}
             roof["frac"] = roof["achieved"] / roof["peak"]
             roof["traffic"] = None
+            try:                                   # PMC pass (tools/pmc_traffic.py), same config only
+                pm = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
+                key = "%s:B%d:sa_conv_gemm_kernel<%s,128,128,1,1>" % (
+                    args.dtype, args.batch, {"bf16": "bf16", "bf16x3": "bf16x3_t", "f32": "float"}[args.dtype])
+                if key in pm:
+                    roof["traffic"] = pm[key]["total_bytes"]
+                    roof["algorithmic_bytes"] = nbytes
+            except Exception:
+                pass
             roof["kernel"] = "sa_conv_gemm_kernel<%s,128,128,1,1>" % {"bf16": "bf16", "bf16x3": "bf16x3_t", "f32": "float"}[args.dtype]
             roof["mfma_flops_executed_per_algorithmic_flop"] = mfma_mult
             roof["avg_us"] = avg_s * 1e6

@@ -57,6 +57,13 @@ typedef struct SaConvArgs {
   int B, Lin, Lout, ntiles;  /* ntiles, rowmin, nrows, wlo_off are filled in by the library */
   int rowmin, nrows, wlo_off;
   SaTaps taps;
+  /* fused backward epilogue (dgrad launches): ep_mode 0 = off; 1 = g' = (acc + ep_g2) * swish'(z),
+   * z = ep_x*ep_s1[b][c] + ep_t1[b][c]; 2 = g' = acc + ep_g2.  g' is what is stored in y, and stats
+   * becomes (sum g', sum g'*xhat), xhat = (xv - ep_mean)*ep_rstd with xv = ep_x, or swish(z) when
+   * ep_xp_is_act; ep_mean / ep_rstd are indexed [b*ep_bstride + c] (ep_bstride = COUT or 0). */
+  int ep_mode, ep_xp_is_act, ep_bstride;
+  const void* ep_x; const void* ep_g2;
+  const float* ep_s1; const float* ep_t1; const float* ep_mean; const float* ep_rstd;
 } SaConvArgs;
 
 int sa_conv_gemm(int dtype, int cin, int cout, int sa, int u, const SaConvArgs* a, void* stream);

@@ -28,7 +28,9 @@ class SaConvArgs(C.Structure):
                 ("s1", vp), ("t1", vp), ("s2", vp), ("t2", vp),
                 ("swish", C.c_int), ("relu", C.c_int), ("stats", vp),
                 ("B", C.c_int), ("Lin", C.c_int), ("Lout", C.c_int), ("ntiles", C.c_int),
-                ("rowmin", C.c_int), ("nrows", C.c_int), ("wlo_off", C.c_int), ("taps", SaTaps)]
+                ("rowmin", C.c_int), ("nrows", C.c_int), ("wlo_off", C.c_int), ("taps", SaTaps),
+                ("ep_mode", C.c_int), ("ep_xp_is_act", C.c_int), ("ep_bstride", C.c_int),
+                ("ep_x", vp), ("ep_g2", vp), ("ep_s1", vp), ("ep_t1", vp), ("ep_mean", vp), ("ep_rstd", vp)]
 
 
 class SaWgradArgs(C.Structure):

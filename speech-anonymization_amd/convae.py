@@ -254,10 +254,14 @@ class _ConvAEFn(torch.autograd.Function):
             if need[key]:
                 G[key] = ops.fin_bias(ops.sum_partials(stats, B), B, C, newg(key))
 
-        def in_block(g, y, nrm, C, Ln, prefix, bias_key, g2=None):
-            """backward of [conv -> InstanceNorm(prefix) -> swish] w.r.t. the conv output y."""
+        def in_ep(y, nrm, g2=None):
+            """fused-epilogue description of an [InstanceNorm -> swish] backward (stats pass)."""
             mean, rstd, scale, shift = nrm
-            st = ops.ew("stats", g, y, C, out=g, g2=g2, s1=scale, t1=shift, mean=mean, rstd=rstd, actbwd=True)
+            return dict(mode=1, x=y, g2=g2, s1=scale, t1=shift, mean=mean, rstd=rstd)
+
+        def in_finish(g, st, y, nrm, C, Ln, prefix, bias_key):
+            """g = d z (already multiplied by swish'), st = partial (sum dz, sum dz*yhat)."""
+            mean, rstd = nrm[0], nrm[1]
             sums = ops.sum_partials(st, B)
             dg, db = newg(prefix + ".weight"), newg(prefix + ".bias")
             c1, c2, c3 = ops.fin_norm_bwd(sums, sums, B * C, C, Ln, P[prefix + ".weight"], mean, rstd,
@@ -267,13 +271,24 @@ class _ConvAEFn(torch.autograd.Function):
             bias_from(st2, bias_key, C)
             return g                                             # now d y
 
-        def bn_block(g, r, bn, Ln, prefix, bias_key, xp=None):
+        def in_block(g, y, nrm, C, Ln, prefix, bias_key):
+            """unfused form (the incoming gradient does not come from sa_conv_gemm)."""
+            mean, rstd, scale, shift = nrm
+            st = ops.ew("stats", g, y, C, out=g, s1=scale, t1=shift, mean=mean, rstd=rstd, actbwd=True)
+            return in_finish(g, st, y, nrm, C, Ln, prefix, bias_key)
+
+        def bn_ep(r, bn, xp=None):
+            d = dict(mode=2, x=r, mean=bn[0], rstd=bn[1], per_c=True)
+            if xp:
+                d.update(s1=xp[0], t1=xp[1], xp_is_act=True)
+            return d
+
+        def bn_finish(g, st, r, bn, Ln, prefix, bias_key, xp=None):
             """backward of [conv -> ReLU -> BatchNorm(prefix)] w.r.t. the conv output (stored r =
             relu output); xp=(s1,t1): the BN input is swish(r*s1+t1) instead (the `norm` BN on the
             encoder output, with GradReverse in front: sign -1, no ReLU mask)."""
             mean, rstd = bn[0], bn[1]
             kw = dict(s1=xp[0], t1=xp[1], xp_is_act=True) if xp else {}
-            st = ops.ew("stats", g, r, 128, mean=mean, rstd=rstd, per_c=True, **kw)
             lsums = ops.sum_partials(st, 1)
             gsums = lsums.clone()
             w = model._bn_allreduce(gsums)
@@ -290,43 +305,19 @@ class _ConvAEFn(torch.autograd.Function):
         def conv_wgrad(key, x, dy, cin, cout, sa, Mrows, K, dil, pad, **pro):
             if need[key]:
                 G[key] = wg(x, dy, cin, cout, sa, 1, [(k * dil - pad, 0) for k in range(K)], Mrows,
-                                   newg(key), (K, cin * K, 1), **pro)
+                            newg(key), (K, cin * K, 1), **pro)
 
         def convT_wgrad(key, x, dy, cin, cout, Mrows):
             if need[key]:
                 G[key] = wg(x, dy, cin, cout, 1, 2, CONVT_WG_TAPS, Mrows, newg(key), (cout * K5, K5, 1))
 
-        # ======================= decoder =======================
         if d_recon is None:
             d_recon = torch.zeros(B, T, 80, device=dev)
         if d_logp is None:
             d_logp = torch.zeros(B, 2, device=dev)
-        g_rec = d_recon.reshape(B, Ltot).contiguous().float()
-        if need["decoder.8.bias"]:
-            setg("decoder.8.bias", ops.sum_partials(g_rec, 1, n=80).sum())
-        if need["decoder.8.weight"]:
-            G["decoder.8.weight"] = ops.wgrad1C(g_rec, y8, newg("decoder.8.weight"), flip=True,
-                                                s1=n8[2], t1=n8[3], swish=True)
-        g = ops.conv1toC(g_rec, P["decoder.8.weight"], None, dt, flip=True)                # d a8
-        g = in_block(g, y8, n8, 32, Ltot, "decoder.6", "decoder.5.bias")                    # d y8
-        convT_wgrad("decoder.5.weight", y7, g, 64, 32, L2)
-        g, st = cg(g, pw("decoder.5.weight", "convT_dgrad"), None, 32, 64, 2, 1,
-                              ops.taps_convT_dgrad(), L2, want_stats=True)                   # d y7
-        bias_from(st, "decoder.4.bias", 64)
-        conv_wgrad("decoder.4.weight", y6, g, 64, 64, 1, L2, K5, 1, 2, s1=n6[2], t1=n6[3], swish=True)
-        g = cg(g, pw("decoder.4.weight", "conv_dgrad"), None, 64, 64, 1, 1,
-                          ops.taps_conv_dgrad_s1(K5, 1, 2), L2)                              # d a6
-        g = in_block(g, y6, n6, 64, L2, "decoder.2", "decoder.1.bias")                      # d y6
-        convT_wgrad("decoder.1.weight", y5, g, 128, 64, L4)
-        g, st = cg(g, pw("decoder.1.weight", "convT_dgrad"), None, 64, 128, 2, 1,
-                              ops.taps_convT_dgrad(), L4, want_stats=True)                   # d y5
-        bias_from(st, "decoder.0.bias", 128)
-        conv_wgrad("decoder.0.weight", y4, g, 128, 128, 1, L4, K5, 1, 2, s1=n4[2], t1=n4[3], swish=True)
-        da4_dec = cg(g, pw("decoder.0.weight", "conv_dgrad"), None, 128, 128, 1, 1,
-                                ops.taps_conv_dgrad_s1(K5, 1, 2), L4)
 
-        buckets.reduce_stage("decoder")
-        # ======================= sex classifier =======================
+        # ======================= sex classifier (first: its input gradient is an addend of the
+        # encoder-output gradient that the last decoder dgrad fuses in) =======================
         c = "sex_classifier.classify."
         dLG = ops.log_softmax_bwd(d_logp.contiguous().float(), S["logp"])
         H1, H2 = S["H1"], S["H2"]
@@ -347,38 +338,68 @@ class _ConvAEFn(torch.autograd.Function):
         dP = ops.dense(dH1, P[c + "0.weight"], None, 256, 128, transpose_w=True)
         t = "sex_classifier.tdnn."
         g = ops.pool_bwd(r2, bn2[2], bn2[3], dP, S["pmean"], S["psd"])
-        g = bn_block(g, r2, bn2, Lc, t + "8", t + "6.bias")
+        st = ops.ew("stats", g, r2, 128, mean=bn2[0], rstd=bn2[1], per_c=True)
+        g = bn_finish(g, st, r2, bn2, Lc, t + "8", t + "6.bias")
         conv_wgrad(t + "6.weight", r1, g, 128, 128, 1, Lc, 3, 3, 0, s2=bn1[2], t2=bn1[3])
-        g = cg(g, pw(t + "6.weight", "conv_dgrad"), None, 128, 128, 1, 1,
-                          ops.taps_conv_dgrad_s1(3, 3, 0), Lb)
-        g = bn_block(g, r1, bn1, Lb, t + "5", t + "3.bias")
+        g, st = cg(g, pw(t + "6.weight", "conv_dgrad"), None, 128, 128, 1, 1,
+                   ops.taps_conv_dgrad_s1(3, 3, 0), Lb, want_stats=True, ep=bn_ep(r1, bn1))
+        g = bn_finish(g, st, r1, bn1, Lb, t + "5", t + "3.bias")
         conv_wgrad(t + "3.weight", r0, g, 128, 128, 1, Lb, 3, 2, 0, s2=bn0[2], t2=bn0[3])
-        g = cg(g, pw(t + "3.weight", "conv_dgrad"), None, 128, 128, 1, 1,
-                          ops.taps_conv_dgrad_s1(3, 2, 0), La)
-        g = bn_block(g, r0, bn0, La, t + "2", t + "0.bias")
+        g, st = cg(g, pw(t + "3.weight", "conv_dgrad"), None, 128, 128, 1, 1,
+                   ops.taps_conv_dgrad_s1(3, 2, 0), La, want_stats=True, ep=bn_ep(r0, bn0))
+        g = bn_finish(g, st, r0, bn0, La, t + "2", t + "0.bias")
         conv_wgrad(t + "0.weight", y4, g, 128, 128, 1, La, 5, 1, 0, s1=n4[2], t1=n4[3], swish=True,
                    s2=bn_n[2], t2=bn_n[3])
-        g = cg(g, pw(t + "0.weight", "conv_dgrad"), None, 128, 128, 1, 1,
-                          ops.taps_conv_dgrad_s1(5, 1, 0), L4)
-        da4_cls = bn_block(g, y4, bn_n, L4, "sex_classifier.norm", None, xp=(n4[2], n4[3]))   # includes GRL
-
+        xp4 = (n4[2], n4[3])
+        g, st = cg(g, pw(t + "0.weight", "conv_dgrad"), None, 128, 128, 1, 1,
+                   ops.taps_conv_dgrad_s1(5, 1, 0), L4, want_stats=True, ep=bn_ep(y4, bn_n, xp4))
+        da4_cls = bn_finish(g, st, y4, bn_n, L4, "sex_classifier.norm", None, xp=xp4)      # includes GRL
         buckets.reduce_stage("sex_classifier")
+
+        # ======================= decoder =======================
+        g_rec = d_recon.reshape(B, Ltot).contiguous().float()
+        if need["decoder.8.bias"]:
+            setg("decoder.8.bias", ops.sum_partials(g_rec, 1, n=80).sum())
+        if need["decoder.8.weight"]:
+            G["decoder.8.weight"] = ops.wgrad1C(g_rec, y8, newg("decoder.8.weight"), flip=True,
+                                                s1=n8[2], t1=n8[3], swish=True)
+        g = ops.conv1toC(g_rec, P["decoder.8.weight"], None, dt, flip=True)                # d a8
+        g = in_block(g, y8, n8, 32, Ltot, "decoder.6", "decoder.5.bias")                    # d y8
+        convT_wgrad("decoder.5.weight", y7, g, 64, 32, L2)
+        g, st = cg(g, pw("decoder.5.weight", "convT_dgrad"), None, 32, 64, 2, 1,
+                   ops.taps_convT_dgrad(), L2, want_stats=True)                              # d y7
+        bias_from(st, "decoder.4.bias", 64)
+        conv_wgrad("decoder.4.weight", y6, g, 64, 64, 1, L2, K5, 1, 2, s1=n6[2], t1=n6[3], swish=True)
+        g, st = cg(g, pw("decoder.4.weight", "conv_dgrad"), None, 64, 64, 1, 1,
+                   ops.taps_conv_dgrad_s1(K5, 1, 2), L2, want_stats=True, ep=in_ep(y6, n6))  # d z6
+        g = in_finish(g, st, y6, n6, 64, L2, "decoder.2", "decoder.1.bias")                 # d y6
+        convT_wgrad("decoder.1.weight", y5, g, 128, 64, L4)
+        g, st = cg(g, pw("decoder.1.weight", "convT_dgrad"), None, 64, 128, 2, 1,
+                   ops.taps_convT_dgrad(), L4, want_stats=True)                              # d y5
+        bias_from(st, "decoder.0.bias", 128)
+        conv_wgrad("decoder.0.weight", y4, g, 128, 128, 1, L4, K5, 1, 2, s1=n4[2], t1=n4[3], swish=True)
+        buckets.reduce_stage("decoder")
+
         # ======================= encoder =======================
-        g = in_block(da4_dec, y4, n4, 128, L4, "encoder.12", "encoder.11.bias", g2=da4_cls)  # d y4
+        # d z4 = (decoder.0 dgrad + classifier branch) * swish'(z4), fused into the dgrad launch
+        g, st = cg(g, pw("decoder.0.weight", "conv_dgrad"), None, 128, 128, 1, 1,
+                   ops.taps_conv_dgrad_s1(K5, 1, 2), L4, want_stats=True, ep=in_ep(y4, n4, g2=da4_cls))
+        g = in_finish(g, st, y4, n4, 128, L4, "encoder.12", "encoder.11.bias")               # d y4
         conv_wgrad("encoder.11.weight", y3, g, 128, 128, 1, L4, K5, 1, 2, s1=n3[2], t1=n3[3], swish=True)
-        g = cg(g, pw("encoder.11.weight", "conv_dgrad"), None, 128, 128, 1, 1,
-                          ops.taps_conv_dgrad_s1(K5, 1, 2), L4)
-        g = in_block(g, y3, n3, 128, L4, "encoder.9", "encoder.8.bias")                      # d y3
+        g, st = cg(g, pw("encoder.11.weight", "conv_dgrad"), None, 128, 128, 1, 1,
+                   ops.taps_conv_dgrad_s1(K5, 1, 2), L4, want_stats=True, ep=in_ep(y3, n3))
+        g = in_finish(g, st, y3, n3, 128, L4, "encoder.9", "encoder.8.bias")                 # d y3
         conv_wgrad("encoder.8.weight", y2, g, 64, 128, 2, L4, K5, 1, 2, s1=n2[2], t1=n2[3], swish=True)
-        g = cg(g, pw("encoder.8.weight", "conv_dgrad"), None, 128, 64, 1, 2, ops.UP2, L2)
-        g = in_block(g, y2, n2, 64, L2, "encoder.6", "encoder.5.bias")                       # d y2
+        g, st = cg(g, pw("encoder.8.weight", "conv_dgrad"), None, 128, 64, 1, 2, ops.UP2, L2,
+                   want_stats=True, ep=in_ep(y2, n2))
+        g = in_finish(g, st, y2, n2, 64, L2, "encoder.6", "encoder.5.bias")                  # d y2
         conv_wgrad("encoder.5.weight", y1, g, 64, 64, 1, L2, K5, 1, 2, s1=n1[2], t1=n1[3], swish=True)
-        g = cg(g, pw("encoder.5.weight", "conv_dgrad"), None, 64, 64, 1, 1,
-                          ops.taps_conv_dgrad_s1(K5, 1, 2), L2)
-        g = in_block(g, y1, n1, 64, L2, "encoder.3", "encoder.2.bias")                       # d y1
+        g, st = cg(g, pw("encoder.5.weight", "conv_dgrad"), None, 64, 64, 1, 1,
+                   ops.taps_conv_dgrad_s1(K5, 1, 2), L2, want_stats=True, ep=in_ep(y1, n1))
+        g = in_finish(g, st, y1, n1, 64, L2, "encoder.3", "encoder.2.bias")                  # d y1
         conv_wgrad("encoder.2.weight", y0, g, 32, 64, 2, L2, K5, 1, 2, swish=True)
-        g = cg(g, pw("encoder.2.weight", "conv_dgrad"), None, 64, 32, 1, 2, ops.UP2, Ltot)
-        st = ops.ew("stats", g, y0, 32, out=g, actbwd=True)                                  # d y0
+        g, st = cg(g, pw("encoder.2.weight", "conv_dgrad"), None, 64, 32, 1, 2, ops.UP2, Ltot,
+                   want_stats=True, ep=dict(mode=1, x=y0))                                   # d y0
         bias_from(st, "encoder.0.bias", 32)
         if need["encoder.0.weight"]:
             G["encoder.0.weight"] = ops.wgrad1C(S["x0"], g, newg("encoder.0.weight"))

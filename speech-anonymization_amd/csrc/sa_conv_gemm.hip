@@ -195,6 +195,25 @@ __global__ __launch_bounds__(256) void sa_conv_gemm_kernel(SaConvArgs a, int red
       }
     }
   }
+  // fused backward epilogue (ep_mode != 0): the stored forward tensor (and an optional second
+  // gradient) of this thread's output chunks are requested now, so the loads fly during the
+  // accumulator transpose below
+  constexpr int NOT = TM / C::RPPO;
+  const int ec = tid % C::CHO, er0 = tid / C::CHO;
+  uint4 epx[NOT], epg[NOT];
+  if (a.ep_mode) {
+    const S* xe = reinterpret_cast<const S*>(a.ep_x) + (size_t)b * a.Lout * COUT + ec * OVEC;
+    const S* ge = a.ep_g2 ? reinterpret_cast<const S*>(a.ep_g2) + (size_t)b * a.Lout * COUT + ec * OVEC : nullptr;
+#pragma unroll
+    for (int i = 0; i < NOT; ++i) {
+      const int o = m0 * U + er0 + i * C::RPPO;
+      epx[i] = make_uint4(0, 0, 0, 0); epg[i] = make_uint4(0, 0, 0, 0);
+      if (o < a.Lout) {
+        epx[i] = *reinterpret_cast<const uint4*>(xe + (size_t)o * COUT);
+        if (ge) epg[i] = *reinterpret_cast<const uint4*>(ge + (size_t)o * COUT);
+      }
+    }
+  }
   __syncthreads();                                   // every wave is done reading As
 
   // ---------------- epilogue: bias/ReLU -> LDS transpose -> coalesced store ------
@@ -217,22 +236,52 @@ __global__ __launch_bounds__(256) void sa_conv_gemm_kernel(SaConvArgs a, int red
   }
   __syncthreads();
   {
-    const int c = tid % C::CHO, r0 = tid / C::CHO;
-    float ssum[OVEC], ssq[OVEC];
+    const int c = ec, r0 = er0;
+    float ssum[OVEC], ssq[OVEC], es1[OVEC], et1[OVEC], emu[OVEC], ers[OVEC];
 #pragma unroll
-    for (int j = 0; j < OVEC; ++j) { ssum[j] = 0.0f; ssq[j] = 0.0f; }
+    for (int j = 0; j < OVEC; ++j) {
+      ssum[j] = 0.0f; ssq[j] = 0.0f;
+      es1[j] = (a.ep_mode && a.ep_s1) ? a.ep_s1[(size_t)b * COUT + c * OVEC + j] : 1.0f;
+      et1[j] = (a.ep_mode && a.ep_t1) ? a.ep_t1[(size_t)b * COUT + c * OVEC + j] : 0.0f;
+      emu[j] = (a.ep_mode && a.ep_mean) ? a.ep_mean[(size_t)b * a.ep_bstride + c * OVEC + j] : 0.0f;
+      ers[j] = (a.ep_mode && a.ep_rstd) ? a.ep_rstd[(size_t)b * a.ep_bstride + c * OVEC + j] : 1.0f;
+    }
     S* yb = reinterpret_cast<S*>(a.y) + (size_t)b * a.Lout * COUT + c * OVEC;
     const int o0 = m0 * U;
-    for (int r = r0; r < TM; r += C::RPPO) {
-      const int o = o0 + r;
-      if (o < a.Lout) {
-        const uint4 u = *reinterpret_cast<const uint4*>(Os + (size_t)r * C::OPITCH + c * OVEC);
-        *reinterpret_cast<uint4*>(yb + (size_t)o * COUT) = u;
-        if (a.stats) {
-          float f[OVEC];
-          tr::unpack(u, f);
 #pragma unroll
-          for (int j = 0; j < OVEC; ++j) { ssum[j] += f[j]; ssq[j] = fmaf(f[j], f[j], ssq[j]); }
+    for (int i = 0; i < NOT; ++i) {
+      const int r = r0 + i * C::RPPO, o = o0 + r;
+      if (o < a.Lout) {
+        uint4 u = *reinterpret_cast<const uint4*>(Os + (size_t)r * C::OPITCH + c * OVEC);
+        if (a.ep_mode) {
+          // mode 1: g' = (g + g2) * swish'(z), xhat from x (InstanceNorm + x*sigmoid(x) block)
+          // mode 2: g' = g + g2, xhat from x, or from swish(z) when ep_xp_is_act (BatchNorm blocks)
+          float g[OVEC], x[OVEC], g2[OVEC], xn[OVEC];
+          tr::unpack(u, g); tr::unpack(epx[i], x); tr::unpack(epg[i], g2);
+#pragma unroll
+          for (int j = 0; j < OVEC; ++j) {
+            const float z = fmaf(x[j], es1[j], et1[j]);
+            float gg = g[j] + g2[j];
+            if (a.ep_mode == 1) gg *= sa_swish_grad(z);
+            const float xv = a.ep_xp_is_act ? sa_swish(z) : x[j];
+            xn[j] = (xv - emu[j]) * ers[j];
+            g[j] = gg;
+          }
+          u = tr::pack(g);
+          *reinterpret_cast<uint4*>(yb + (size_t)o * COUT) = u;
+          if (a.stats) {
+            tr::unpack(u, g);
+#pragma unroll
+            for (int j = 0; j < OVEC; ++j) { ssum[j] += g[j]; ssq[j] = fmaf(g[j], xn[j], ssq[j]); }
+          }
+        } else {
+          *reinterpret_cast<uint4*>(yb + (size_t)o * COUT) = u;
+          if (a.stats) {
+            float f[OVEC];
+            tr::unpack(u, f);
+#pragma unroll
+            for (int j = 0; j < OVEC; ++j) { ssum[j] += f[j]; ssq[j] = fmaf(f[j], f[j], ssq[j]); }
+          }
         }
       }
     }
@@ -336,6 +385,7 @@ extern "C" int sa_conv_gemm(int dtype, int cin, int cout, int sa, int u, const S
                             void* stream) {
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   if (!a || !a->x || !a->wp || !a->y || a->B <= 0 || a->Lin <= 0 || a->Lout <= 0) return -22;
+  if (a->ep_mode < 0 || a->ep_mode > 2 || (a->ep_mode && !a->ep_x)) return -22;
   SA_CONV_CASE(32, 64, 2, 1)
   SA_CONV_CASE(64, 64, 1, 1)
   SA_CONV_CASE(64, 128, 2, 1)

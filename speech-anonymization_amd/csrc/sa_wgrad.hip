@@ -140,7 +140,17 @@ __global__ __launch_bounds__(256) void sa_wgrad_kernel(SaWgradArgs a) {
   __shared__ __attribute__((aligned(16))) LT Bt[NPL * C::RB * PB];
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int chunk = blockIdx.x, sub = blockIdx.y, b = blockIdx.z;
+  // The NSUB channel sub-blocks of one (utterance, row chunk) read the same rows.  Workgroups are
+  // dealt round-robin over the 8 XCDs, so siblings are given linear ids that differ by 8 (same
+  // XCD L2, dispatched close together): id = group*8*NSUB + sub*8 + lane, tile = group*8 + lane.
+  // Pure speed: any placement computes the same slabs.
+  constexpr int NSUB = (CIN / C::MS) * (COUT / C::NS);
+  const int lin = blockIdx.x;
+  const int grp = lin / (8 * NSUB), rem = lin % (8 * NSUB);
+  const int tile = grp * 8 + rem % 8, sub = rem / 8;
+  const int ntile = a.nchunk * a.B;
+  if (tile >= ntile) return;
+  const int chunk = tile % a.nchunk, b = tile / a.nchunk;
   const int cm0 = (sub / (COUT / C::NS)) * C::MS, cn0 = (sub % (COUT / C::NS)) * C::NS;
   const int mbeg = chunk * a.chunk;
   int mend = mbeg + a.chunk; if (mend > a.Mrows) mend = a.Mrows;
@@ -313,7 +323,8 @@ static int launch_wgrad(const SaWgradArgs& a, hipStream_t st) {
   }
   if (omax - omin > C::HALO) return -22;
   for (int t = 0; t < a.ntaps; ++t) if (a.ph[t] < 0 || a.ph[t] >= U) return -22;
-  dim3 grid(a.nchunk, (CIN / C::MS) * (COUT / C::NS), a.B);
+  const int nsub = (CIN / C::MS) * (COUT / C::NS);
+  dim3 grid(sa_div_up(a.nchunk * a.B, 8) * 8 * nsub);
   hipLaunchKernelGGL((sa_wgrad_kernel<T, CIN, COUT, SA, U>), grid, dim3(256), 0, st, a);
   hipError_t e = hipGetLastError();
   return e == hipSuccess ? 0 : -(int)e;

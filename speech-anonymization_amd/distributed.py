@@ -6,8 +6,8 @@ the DistributedDataParallel / SyncBatchNorm wrap inside Brain.
 The path shards by utterance: each rank runs the whole step on its own B utterances; the only
 exchanges are (1) the tiny BatchNorm statistic sums of the classifier (SyncBatchNorm semantics,
 convae.ConvAutoencoder._bn_allreduce) and (2) the gradient average.  Gradients are written by
-the backward kernels straight into three flat fp32 stage buckets (decoder 0.62 MB, classifier
-0.89 MB, encoder 0.62 MB); each bucket is all-reduced on a SIDE stream as soon as its stage is
+the backward kernels straight into three flat fp32 stage buckets (classifier 0.89 MB, decoder
+0.62 MB, encoder 0.62 MB, in completion order); each bucket is all-reduced on a SIDE stream as soon as its stage is
 complete, so the collective (latency-bound at this size) overlaps the rest of backward, and the
 main stream joins the side stream once, before the optimizer touches the gradients.
 """
@@ -51,7 +51,10 @@ def ddp_init_group(run_opts=None):
     if ws > 1 and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
-        backend = run_opts.get("distributed_backend") or ("nccl" if torch.cuda.is_available() else "gloo")
+        backend = (run_opts.get("distributed_backend") or os.environ.get("SA_DIST_BACKEND")
+                   or ("nccl" if torch.cuda.is_available() else "gloo"))
+        if os.environ.get("SA_SAME_DEVICE") == "1":   # rehearsal: several ranks share GPU 0 (gloo only)
+            lr = 0
         if backend == "nccl":
             torch.cuda.set_device(lr)
             dist.init_process_group(backend, rank=rk, world_size=ws,

@@ -103,8 +103,10 @@ def pack_weights(w, kind, dtype, code=None):
 
 
 def conv_gemm(x, wp, bias, cin, cout, sa, u, phases, Lout, s1=None, t1=None, s2=None, t2=None,
-              swish=False, relu=False, want_stats=False, out=None, code=None):
-    """x [B, Lin, cin] -> y [B, Lout, cout] (+ per-tile partial stats [B, ntiles, cout, 2])."""
+              swish=False, relu=False, want_stats=False, out=None, code=None, ep=None):
+    """x [B, Lin, cin] -> y [B, Lout, cout] (+ per-tile partial stats [B, ntiles, cout, 2]).
+    ep: fused backward epilogue dict(mode=1|2, x=, g2=, s1=, t1=, mean=, rstd=, xp_is_act=,
+    per_c=) -- see SaConvArgs.ep_* in include/sa_hip.h."""
     lib = L.load()
     B, Lin, _ = x.shape
     assert x.shape[2] == cin
@@ -117,6 +119,12 @@ def conv_gemm(x, wp, bias, cin, cout, sa, u, phases, Lout, s1=None, t1=None, s2=
     a.swish, a.relu, a.stats = int(swish), int(relu), _f(stats)
     a.B, a.Lin, a.Lout = B, Lin, Lout
     a.taps = L.make_taps(phases)
+    if ep:
+        a.ep_mode, a.ep_xp_is_act = int(ep["mode"]), int(bool(ep.get("xp_is_act")))
+        a.ep_bstride = 0 if ep.get("per_c") else cout
+        a.ep_x, a.ep_g2 = _f(ep["x"]), _f(ep.get("g2"))
+        a.ep_s1, a.ep_t1 = _f(ep.get("s1")), _f(ep.get("t1"))
+        a.ep_mean, a.ep_rstd = _f(ep.get("mean")), _f(ep.get("rstd"))
     e0 = PROFILE.start(f"conv_gemm({cin},{cout},{sa},{u})") if PROFILE.key else None
     L.check(lib.sa_conv_gemm(L.dt_code(x.dtype) if code is None else code, cin, cout, sa, u,
                              C.byref(a), L.stream()),

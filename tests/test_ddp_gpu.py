@@ -1,0 +1,85 @@
+"""Data-parallel path end to end on ONE GPU: two ranks share cuda:0 and exchange through gloo
+(RCCL needs one GPU per rank; the collectives' call sites, SyncBN statistic exchange, stage
+buckets on the side stream and the gradient average are the same code).  Checks the property
+DESIGN.md section 7 promises: 2 ranks x B utterances == 1 rank x 2B utterances."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _inputs(B, T):
+    from oracle.features import synthetic_feats
+    feats = synthetic_feats(B, T, seed=77)
+    rs = np.random.RandomState(5)
+    target = feats + 0.1 * torch.from_numpy(rs.standard_normal(feats.shape).astype("float32"))
+    return feats, target, torch.arange(B) % 2
+
+
+def _run(model, feats, target, gender):
+    from speech_anonymization_amd import ops
+    recon, logp = model(feats.cuda())
+    loss_r, g_r = ops.recon_loss(recon.detach().contiguous(), target.cuda().contiguous(), "l1")
+    out, dn, _ = ops.cls_losses(logp.detach(), gender.cuda())
+    torch.autograd.backward([recon, logp], [0.1 * g_r.view_as(recon), 0.9 * dn])
+    torch.cuda.synchronize()
+    return {k: p.grad.detach().cpu() for k, p in model.named_parameters()}, \
+           {k: v.detach().cpu() for k, v in model.state_dict().items() if "running" in k}
+
+
+def _worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank), SA_DIST_BACKEND="gloo", SA_SAME_DEVICE="1")
+    sys.path.insert(0, ROOT)
+    from oracle.convae import numpy_params
+    from speech_anonymization_amd import distributed as sdist
+    from speech_anonymization_amd.convae import ConvAutoencoder
+    sdist.ddp_init_group()
+    torch.cuda.set_device(0)
+    m = ConvAutoencoder(precision="f32", pooling_noise=None)
+    m.load_state_dict(numpy_params(8886))
+    m.cuda().train()
+    feats, target, gender = _inputs(6, 72)
+    lo, hi = sdist.shard_batch(6, rank, world)
+    grads, bufs = _run(m, feats[lo:hi], target[lo:hi], gender[lo:hi])
+    q.put((rank, {k: v.numpy() for k, v in grads.items()}, {k: v.numpy() for k, v in bufs.items()}))
+    torch.distributed.barrier()
+    torch.distributed.destroy_process_group()
+
+
+def test_two_ranks_equal_one_rank_with_double_batch():
+    import torch.multiprocessing as mp
+    from oracle.convae import numpy_params
+    from speech_anonymization_amd.convae import ConvAutoencoder
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29600 + (os.getpid() % 1000)
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=300) for _ in procs], key=lambda r: r[0])
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    m = ConvAutoencoder(precision="f32", pooling_noise=None)
+    m.load_state_dict(numpy_params(8886))
+    m.cuda().train()
+    feats, target, gender = _inputs(6, 72)
+    ref, ref_bufs = _run(m, feats, target, gender)
+
+    def rel(a, b):
+        a, b = torch.as_tensor(a).double(), b.double()
+        return float(((a - b) ** 2).sum() / (b ** 2).sum().clamp_min(1e-30))
+    from tests.test_convae_gpu import NULL_BIAS
+    for k, g in ref.items():
+        if k in NULL_BIAS:
+            continue
+        assert np.array_equal(res[0][1][k], res[1][1][k]), k        # both ranks hold the average
+        assert rel(res[0][1][k], g) < 2e-5, (k, rel(res[0][1][k], g))
+    for k, v in ref_bufs.items():                                    # SyncBN: global statistics
+        assert rel(res[0][2][k], v) < 1e-8, k
