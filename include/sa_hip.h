@@ -26,6 +26,7 @@ extern "C" {
 #define SA_F32 0
 #define SA_BF16 1
 #define SA_BF16X3 2   /* fp32 storage, split-bf16 operands, 3 bf16 MFMAs per k-step */
+#define SA_BF16X1F 3  /* fp32 storage, operands rounded to bf16 once, 1 bf16 MFMA (sa_wgrad only) */
 #define SA_MAX_TAPS 5
 
 /* ---- implicit-GEMM convolution (sa_conv_gemm.hip) -------------------------------------
@@ -128,6 +129,7 @@ int sa_ew_ntiles(int L);
 int sa_act_stats(int dtype, int C, const void* x, const float* s1, const float* t1, int swish,
                  float* stats, int B, int L, void* stream);
 int sa_sum_partials(const float* slabs, double* dst, int nbatch, int nslab, int n, void* stream);
+int sa_sum_rows_d(const double* src, double* dst, int R, int n, void* stream);
 int sa_fin_in_fwd(const double* sums, int B, int C, int n, const float* gamma, const float* beta,
                   float eps, float* mean, float* rstd, float* scale, float* shift, void* stream);
 int sa_fin_bn_fwd(const double* sums, int C, double count, const float* gamma, const float* beta,

@@ -11,7 +11,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libsa_hip.so")
 
-F32, BF16, BF16X3 = 0, 1, 2
+F32, BF16, BF16X3, BF16X1F = 0, 1, 2, 3
 MAX_TAPS = 5
 
 c_fp = C.POINTER(C.c_float)
@@ -55,7 +55,7 @@ SYMBOLS = [
     "sa_conv_gemm", "sa_conv_gemm_ntiles", "sa_conv_gemm_set_tile_rows", "sa_pack_weights", "sa_wgrad", "sa_wgrad_kw", "sa_wgrad_reduce",
     "sa_conv1toC", "sa_conv1toC_ntiles", "sa_convCto1", "sa_wgrad1C", "sa_wgrad1C_nchunk",
     "sa_sum_slabs", "sa_ew_stats", "sa_ew_apply", "sa_ew_ntiles", "sa_act_stats",
-    "sa_sum_partials", "sa_fin_in_fwd", "sa_fin_bn_fwd", "sa_fin_bn_eval", "sa_fin_norm_bwd", "sa_fin_bias",
+    "sa_sum_partials", "sa_sum_rows_d", "sa_fin_in_fwd", "sa_fin_bn_fwd", "sa_fin_bn_eval", "sa_fin_norm_bwd", "sa_fin_bias",
     "sa_pool_fwd", "sa_pool_ntiles", "sa_pool_fin", "sa_pool_bwd", "sa_dense", "sa_colsums",
     "sa_bn2d_bwd", "sa_dense_wgrad", "sa_log_softmax", "sa_log_softmax_bwd",
     "sa_loss_workspace_bytes", "sa_recon_loss", "sa_cls_losses", "sa_cosine_loss",

@@ -248,7 +248,7 @@ class _ConvAEFn(torch.autograd.Function):
             G[key] = newg(key).copy_(val.reshape(P[key].shape))
         pw = lambda k, kind: ops.pack_weights(P[k], kind, dt, model.kcode)
         cg = functools.partial(ops.conv_gemm, code=model.kcode)
-        wg = functools.partial(ops.wgrad, code=model.kcode)
+        wg = functools.partial(ops.wgrad, code=ops.WGRAD_CODE[model.precision])
 
         def bias_from(stats, key, C):
             if need[key]:

@@ -110,6 +110,11 @@ static inline int sa_div_up(int a, int b) { return (a + b - 1) / b; }
 //               hi*hi + lo*hi + hi*lo on the bf16 MFMA: ~16 mantissa bits per operand at 3/16 of
 //               the fp32-MFMA cost.  This is the mode that meets the 1e-4 parity bar.
 struct bf16x3_t {};
+//   SA_BF16X1F: fp32 storage, operands rounded once to bf16 in LDS, one bf16 MFMA per k-step.
+//               Used for WEIGHT GRADIENTS in bf16x3 models: a wgrad inner product sums ~10^5
+//               independent roundings that average out and its result is not propagated through
+//               further layers, so the split buys nothing there (tools/precision_probe.py).
+struct bf16x1f_t {};
 
 template <typename T> struct Pol;
 template <> struct Pol<float> {
@@ -119,6 +124,10 @@ template <> struct Pol<float> {
 template <> struct Pol<bf16_t> {
   typedef bf16_t store_t; typedef bf16_t lds_t; typedef bf16x8 Frag;
   static constexpr int NPL = 1, VEC = 8, KS = 16, PAD = 8;
+};
+template <> struct Pol<bf16x1f_t> {
+  typedef float store_t; typedef bf16_t lds_t; typedef bf16x8 Frag;
+  static constexpr int NPL = 1, VEC = 4, KS = 16, PAD = 8;
 };
 template <> struct Pol<bf16x3_t> {
   typedef float store_t; typedef bf16_t lds_t; typedef bf16x8 Frag;

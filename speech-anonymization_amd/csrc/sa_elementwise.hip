@@ -221,6 +221,23 @@ extern "C" int sa_sum_partials(const float* slabs, double* dst, int nbatch, int 
   return e == hipSuccess ? 0 : -(int)e;
 }
 
+// dst[i] = sum_r src[r][i]  (fp64 in / out; second level of a two-level slab reduction)
+__global__ void sa_sum_rows_d_kernel(const double* __restrict__ src, double* __restrict__ dst, int R, int n) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  double s = 0.0;
+  for (int r = 0; r < R; ++r) s += src[(size_t)r * n + i];
+  dst[i] = s;
+}
+
+extern "C" int sa_sum_rows_d(const double* src, double* dst, int R, int n, void* stream) {
+  if (!src || !dst || R <= 0 || n <= 0) return -22;
+  hipLaunchKernelGGL(sa_sum_rows_d_kernel, dim3(sa_div_up(n, 128)), dim3(128), 0,
+                     reinterpret_cast<hipStream_t>(stream), src, dst, R, n);
+  hipError_t e = hipGetLastError();
+  return e == hipSuccess ? 0 : -(int)e;
+}
+
 // ---------------------------------------------------------------------------------
 // finalisers.  sums layouts: IN  [B][C][2],  BN  [C][2]  (sum, sumsq) or (S1, S2).
 // ---------------------------------------------------------------------------------

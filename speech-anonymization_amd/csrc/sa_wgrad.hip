@@ -182,14 +182,15 @@ __global__ __launch_bounds__(256) void sa_wgrad_kernel(SaWgradArgs a) {
   const S* yb = reinterpret_cast<const S*>(a.dy) + (size_t)b * a.Ldy * COUT + cn0;
   const int dyend = mend * U < a.Ldy ? mend * U : a.Ldy;
 
-  uint4 rawA[C::NITA], rawB[C::NITB];
-  auto issue = [&](int m0) {
+  // two register sets: the rows of K-tiles i+1 and i+2 are in flight while tile i is in the MFMAs
+  uint4 rawA0[C::NITA], rawB0[C::NITB], rawA1[C::NITA], rawB1[C::NITB];
+  auto issue = [&](uint4 (&rawA)[C::NITA], uint4 (&rawB)[C::NITB], int m0) {
 #pragma unroll
     for (int i = 0; i < C::NITA; ++i) {
       const int e = tid + i * 256, r = e / C::CHA, c = e % C::CHA;
       const int g = m0 * SA + offmin + r;
       rawA[i] = make_uint4(0, 0, 0, 0);
-      if (r < C::RA && g >= 0 && g < a.Lin)
+      if (m0 < mend && r < C::RA && g >= 0 && g < a.Lin)
         rawA[i] = *reinterpret_cast<const uint4*>(xb + (size_t)g * CIN + c * VEC);
     }
 #pragma unroll
@@ -197,7 +198,7 @@ __global__ __launch_bounds__(256) void sa_wgrad_kernel(SaWgradArgs a) {
       const int e = tid + i * 256, r = e / C::CHB, c = e % C::CHB;
       const int g = m0 * U + r;
       rawB[i] = make_uint4(0, 0, 0, 0);
-      if (r < C::RB && g < dyend) rawB[i] = *reinterpret_cast<const uint4*>(yb + (size_t)g * COUT + c * VEC);
+      if (m0 < mend && r < C::RB && g < dyend) rawB[i] = *reinterpret_cast<const uint4*>(yb + (size_t)g * COUT + c * VEC);
     }
   };
   auto put = [&](LT* base, int planes_stride, int pitch, int r, int c, const float* f) {
@@ -207,11 +208,13 @@ __global__ __launch_bounds__(256) void sa_wgrad_kernel(SaWgradArgs a) {
       sa_split4(f, hi, lo);
       *reinterpret_cast<uint2*>(dst) = hi;
       *reinterpret_cast<uint2*>(dst + planes_stride) = lo;
+    } else if constexpr (sizeof(S) == 4 && sizeof(LT) == 2) {
+      *reinterpret_cast<uint2*>(dst) = sa_pack_bf16x4(f);
     } else {
       *reinterpret_cast<uint4*>(dst) = tr::pack(f);
     }
   };
-  auto stage = [&](int m0) {
+  auto stage = [&](const uint4 (&rawA)[C::NITA], const uint4 (&rawB)[C::NITB], int m0) {
 #pragma unroll
     for (int i = 0; i < C::NITA; ++i) {
       const int e = tid + i * 256, r = e / C::CHA, c = e % C::CHA;
@@ -247,11 +250,7 @@ __global__ __launch_bounds__(256) void sa_wgrad_kernel(SaWgradArgs a) {
   const int trow = 8 * (g4 >> 1) + (i16 >> 2);             // tr-read: k within the 16-deep step
   const int tcol = 16 * (g4 & 1) + 4 * (i16 & 3);          //          column within the 32-wide tile
 
-  issue(mbeg);
-  for (int m0 = mbeg; m0 < mend; m0 += KT) {
-    stage(m0);
-    __syncthreads();
-    if (m0 + KT < mend) issue(m0 + KT);
+  auto mfma_tile = [&]() {
     for (int ks = kw; ks < KT / KS; ks += C::KW) {
       if constexpr (sizeof(LT) == 2) {
         Frag bh[U], bl[U];
@@ -292,7 +291,22 @@ __global__ __launch_bounds__(256) void sa_wgrad_kernel(SaWgradArgs a) {
         }
       }
     }
+  };
+  issue(rawA0, rawB0, mbeg);
+  issue(rawA1, rawB1, mbeg + KT);
+  for (int m0 = mbeg; m0 < mend; m0 += 2 * KT) {
+    stage(rawA0, rawB0, m0);
     __syncthreads();
+    issue(rawA0, rawB0, m0 + 2 * KT);
+    mfma_tile();
+    __syncthreads();
+    if (m0 + KT < mend) {
+      stage(rawA1, rawB1, m0 + KT);
+      __syncthreads();
+      issue(rawA1, rawB1, m0 + 3 * KT);
+      mfma_tile();
+      __syncthreads();
+    }
   }
 
   // ---- fp32 partial slab [kw][tap][CIN][COUT]; this workgroup writes its MS x NS sub-block ----
@@ -334,6 +348,7 @@ static int launch_wgrad(const SaWgradArgs& a, hipStream_t st) {
   if (cin == CI && cout == CO && sa == S && u == UU)                            \
     return dtype == SA_BF16 ? launch_wgrad<bf16_t, CI, CO, S, UU>(*a, st)       \
            : dtype == SA_BF16X3 ? launch_wgrad<bf16x3_t, CI, CO, S, UU>(*a, st) \
+           : dtype == SA_BF16X1F ? launch_wgrad<bf16x1f_t, CI, CO, S, UU>(*a, st) \
                                 : launch_wgrad<float, CI, CO, S, UU>(*a, st);
 
 extern "C" int sa_wgrad(int dtype, int cin, int cout, int sa, int u, const SaWgradArgs* a,

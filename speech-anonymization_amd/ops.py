@@ -73,6 +73,8 @@ PROFILE = _Profile()
 # precision modes of the MFMA kernels: name -> (activation storage dtype, kernel dtype code)
 PRECISIONS = {"f32": (torch.float32, L.F32), "bf16": (torch.bfloat16, L.BF16),
               "bf16x3": (torch.float32, L.BF16X3)}
+# kernel code of the weight-gradient GEMM per model precision (SA_BF16X1F: see sa_common.h)
+WGRAD_CODE = {"f32": L.F32, "bf16": L.BF16, "bf16x3": L.BF16X1F}
 
 
 def pack_weights(w, kind, dtype, code=None):
@@ -138,7 +140,7 @@ def conv_gemm(x, wp, bias, cin, cout, sa, u, phases, Lout, s1=None, t1=None, s2=
 
 
 def wgrad(x, dy, cin, cout, sa, u, taps, Mrows, dst, dst_strides, s1=None, t1=None, s2=None,
-          t2=None, swish=False, accumulate=False, target_wgs=640, code=None):
+          t2=None, swish=False, accumulate=False, target_wgs=1024, code=None):
     """taps: list of (row_offset, phase) per weight tap.  dst: fp32 parameter-gradient tensor in
     PyTorch layout; dst_strides = (s_ci, s_co, s_tap)."""
     lib = L.load()
@@ -206,6 +208,14 @@ def sum_partials(part, nbatch, n=None):
         n = part.shape[-2] * part.shape[-1]
     total = part.numel()
     nslab = total // (nbatch * n)
+    if nbatch == 1 and nslab >= 512 and part.dim() == 4 and part.shape[0] > 1:
+        # two levels (per utterance, then over utterances): keeps the first level wide
+        R = part.shape[0]
+        mid = torch.empty(R, n, dtype=torch.float64, device=part.device)
+        L.check(lib.sa_sum_partials(_f(part), _f(mid), R, nslab // R, n, L.stream()), "sa_sum_partials")
+        out = torch.empty(1, n, dtype=torch.float64, device=part.device)
+        L.check(lib.sa_sum_rows_d(_f(mid), _f(out), R, n, L.stream()), "sa_sum_rows_d")
+        return out
     out = torch.empty(nbatch, n, dtype=torch.float64, device=part.device)
     L.check(lib.sa_sum_partials(_f(part), _f(out), nbatch, nslab, n, L.stream()), "sa_sum_partials")
     return out

@@ -141,7 +141,8 @@ def test_against_oracle_full_tensors(dt, B, T):
             e = rel_mse(h, o64)
             lim = max(2e-5 if through_classifier else 1e-10, 30 * rel_mse(o32, o64))
         elif dt == "bf16x3":                    # the benchmarked mode: north_star's 1e-4 everywhere
-            e, lim = rel_mse(h, o32), (1e-4 if through_classifier else 1e-8)
+            # decoder weight gradients: single-bf16 wgrad inner products (SA_BF16X1F), ~3e-7
+            e, lim = rel_mse(h, o32), (1e-4 if through_classifier else (1e-8 if k == "recon" else 1e-5))
         else:
             e, lim = rel_mse(h, o32), BF16_LIMIT(k)
         if lim is None:

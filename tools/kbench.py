@@ -61,7 +61,7 @@ for prec in precs:
             else:
                 taps, Mrows, dst, strides = [(k - 2, 0) for k in range(5)], Lout, torch.empty(cout, cin, 5, device=dev), (5, cin * 5, 1)
             f = lambda: ops.wgrad(x, dy, cin, cout, sa, u, taps, Mrows, dst, strides, s1=s1, t1=t1,
-                                  swish=True, code=code)
+                                  swish=True, code=ops.WGRAD_CODE[prec])
             us = timeit(f)
             flops = 2 * B * Mrows * 5 * cin * cout
             byts = (x.numel() + dy.numel()) * x.element_size()
