@@ -1,0 +1,107 @@
+"""Shape edge cases and full-size properties (sizes the CPU oracle cannot finish in seconds are
+checked through size-independent properties and cross-precision agreement)."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def rel_mse(a, b):
+    a, b = a.detach().double().cpu(), b.detach().double().cpu()
+    return float(((a - b) ** 2).sum() / (b ** 2).sum().clamp_min(1e-30))
+
+
+def _model(precision, seed=8886):
+    from speech_anonymization_amd.convae import ConvAutoencoder
+    torch.manual_seed(seed)
+    return ConvAutoencoder(precision=precision, pooling_noise=None).to("cuda:0").train()
+
+
+def _step(m, feats, gender):
+    from speech_anonymization_amd import ops
+    recon, logp = m(feats)
+    _, g_r = ops.recon_loss(recon.detach().contiguous(), feats.contiguous(), "l1")
+    _, dn, _ = ops.cls_losses(logp.detach(), gender)
+    torch.autograd.backward([recon, logp], [0.1 * g_r.view_as(recon), 0.9 * dn])
+    torch.cuda.synchronize()
+    return recon, logp, {k: p.grad for k, p in m.named_parameters()}
+
+
+@pytest.mark.parametrize("B,T", [(1, 36), (2, 36), (5, 252)])
+def test_small_and_odd_batches_match_oracle(B, T):
+    """B = 1 (BatchNorm over one utterance: only the conv/TDNN statistics over L are defined; the
+    FC BatchNorms divide by a zero variance exactly like the reference) is exercised for shape and
+    finiteness of the decoder; B >= 2 is compared with the oracle."""
+    from oracle.convae import ConvAutoencoder as OAE
+    from oracle.features import synthetic_feats
+    feats = synthetic_feats(B, T, seed=T + B)
+    m = _model("f32")
+    if B == 1:
+        m.eval()
+        with torch.no_grad():
+            recon, logp = m(feats.cuda())
+        om = OAE(); om.load_state_dict(m.state_dict()); om.eval()
+        with torch.no_grad():
+            o_recon, o_logp = om(feats)
+        assert rel_mse(recon, o_recon) < 1e-9 and rel_mse(logp, o_logp) < 1e-7
+        return
+    om = OAE(); om.load_state_dict(m.state_dict()); om.train()
+    o_recon, o_logp = om(feats)
+    recon, logp = m(feats.cuda())
+    torch.cuda.synchronize()
+    assert rel_mse(recon, o_recon) < 1e-9 and rel_mse(logp, o_logp) < 1e-5
+
+
+def test_unpadded_T_goes_through_the_pad_to_36_path():
+    """T = 71 frames (N = 11200 samples) is padded to 72 by the fused normalise pass
+    (speechbrain_convae_train.py:62-63); the pad rows are exact zeros and take part in the loss."""
+    import speech_anonymization_amd as pkg
+    from oracle import features as OF
+    wav = OF.synthetic_wave(2, 11200, seed=3)
+    fb, nrm = pkg.Fbank().cuda(), pkg.InputNormalization("global", 4).cuda()
+    f = nrm(fb(wav.cuda()), torch.ones(2), epoch=1, pad_multiple=36)
+    assert f.shape == (2, 72, 80) and float(f[:, 71].abs().max()) == 0.0
+    ofb, onrm = OF.Fbank(), OF.InputNormalization(update_until_epoch=4)
+    ref = OF.pad_to_multiple(onrm(ofb(wav), torch.ones(2), epoch=1), 36)
+    assert rel_mse(f, ref) < 1e-8
+
+
+def test_full_size_properties_30s_utterances():
+    """BASELINE config 5 shape (B = 8, N = 480 000 -> T = 3001 -> 3024): no oracle at this size.
+    Properties: (1) InstanceNorm statistics of every normalised layer, recomputed in fp64 from the
+    stored conv outputs, equal the fused epilogue statistics; (2) the bf16x3 and exact-f32 modes
+    agree on outputs and gradients; (3) the log-probabilities normalise."""
+    import speech_anonymization_amd as pkg
+    from tests import smoke_step
+    B, N = 8, 480000
+    wav = smoke_step.make_wave(B, N, seed=11).cuda()
+    fb, nrm = pkg.Fbank().cuda(), pkg.InputNormalization("global", 4).cuda()
+    feats = nrm(fb(wav), torch.ones(B), epoch=1, pad_multiple=36)
+    assert feats.shape == (B, 3024, 80)
+    gender = (torch.arange(B) % 2).cuda()
+    m32, m3 = _model("f32"), _model("bf16x3")
+    m3.load_state_dict(m32.state_dict())
+    r32, l32, g32 = _step(m32, feats, gender)
+    r3, l3, g3 = _step(m3, feats, gender)
+    assert torch.isfinite(r32).all() and torch.isfinite(l32).all()
+    assert torch.allclose(l32.exp().sum(1), torch.ones(B, device="cuda"), atol=1e-5)
+    assert rel_mse(r3, r32) < 1e-8 and rel_mse(l3, l32) < 1e-6
+    from tests.test_convae_gpu import NULL_BIAS
+    worst = max(rel_mse(g3[k], g32[k]) for k in g32 if k not in NULL_BIAS)
+    assert worst < 1e-4, worst
+
+
+def test_instance_norm_epilogue_statistics_at_scale():
+    from speech_anonymization_amd import ops
+    B, L, C = 4, 60480, 64
+    x = torch.randn(B, L, 32, device="cuda")
+    w = torch.randn(C, 32, 5, device="cuda") * 0.1
+    wp = ops.pack_weights(w, "conv_fwd", torch.float32, ops.PRECISIONS["bf16x3"][1])
+    y, st = ops.conv_gemm(x, wp, None, 32, 64, 2, 1, ops.taps_conv(5, 1, 2), L // 2, want_stats=True,
+                          code=ops.PRECISIONS["bf16x3"][1])
+    sums = ops.sum_partials(st, B).view(B, C, 2)
+    torch.cuda.synchronize()
+    yd = y.double()
+    assert torch.allclose(sums[..., 0], yd.sum(1), rtol=1e-6, atol=1e-4)
+    assert torch.allclose(sums[..., 1], (yd * yd).sum(1), rtol=1e-6, atol=1e-4)

@@ -8,7 +8,7 @@ from speech_anonymization_amd import ops
 dev = torch.device("cuda:0")
 what = (sys.argv[1] if len(sys.argv) > 1 else "all") if __name__ == "__main__" else "none"
 precs = (sys.argv[2] if len(sys.argv) > 2 else "bf16x3,bf16,f32").split(",")
-B, L4 = 10, 20160
+B, L4 = int(__import__("os").environ.get("KB_B", "10")), 20160
 
 
 def timeit(fn, n=20):

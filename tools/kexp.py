@@ -5,7 +5,7 @@ import torch
 from speech_anonymization_amd import ops
 from tools.kbench import timeit
 dev = torch.device("cuda:0")
-B, L4 = 10, 20160
+B, L4 = int(__import__("os").environ.get("KB_B", "10")), 20160
 from speech_anonymization_amd import _lib
 for tm in (128, 64):
   _lib.load().sa_conv_gemm_set_tile_rows(tm)
