@@ -117,6 +117,8 @@ __global__ __launch_bounds__(256) void sa_conv_gemm_kernel(SaConvArgs a, int red
           sa_split4(f, hi, lo);
           *reinterpret_cast<uint2*>(dst) = hi;
           *reinterpret_cast<uint2*>(dst + plane) = lo;
+        } else if constexpr (sizeof(LT) == 2 && sizeof(S) == 4) {
+          *reinterpret_cast<uint2*>(dst) = sa_pack_bf16x4(f);
         } else if constexpr (sizeof(LT) == 2) {
           *reinterpret_cast<uint4*>(dst) = tr::pack(f);
         } else {
@@ -155,7 +157,8 @@ __global__ __launch_bounds__(256) void sa_conv_gemm_kernel(SaConvArgs a, int red
                       + (lane >> 5) * (C::KS / 2);
     auto load_group = [&](Frag (&dst)[P::NPL][KU], int g) {
       const int ti = g / GPT, kg = g % GPT;
-      const Frag* wt = wp + (((size_t)a.taps.widx[ph][ti] * C::KSTEPS + kg * KU) * C::NT + nt) * 64 + lane;
+      const int ntw = (a.relu & 2) ? 0 : nt;     // (debug knob: all waves read the same weight slice)
+      const Frag* wt = wp + (((size_t)a.taps.widx[ph][ti] * C::KSTEPS + kg * KU) * C::NT + ntw) * 64 + lane;
 #pragma unroll
       for (int ku = 0; ku < KU; ++ku) {
         dst[0][ku] = wt[(size_t)ku * C::NT * 64];
@@ -164,22 +167,29 @@ __global__ __launch_bounds__(256) void sa_conv_gemm_kernel(SaConvArgs a, int red
     };
     auto compute_group = [&](const Frag (&bq)[P::NPL][KU], int g) {
       const int ti = g / GPT, kg = g % GPT;
-      const LT* arow = abase + (size_t)a.taps.off[ph][ti] * C::APITCH
-                       + kg * KU * C::KS;
-#pragma unroll
-      for (int ku = 0; ku < KU; ++ku) {
+      const LT* arow = abase + (size_t)a.taps.off[ph][ti] * C::APITCH + kg * KU * C::KS;
+      // A fragments of k-step ku+1 are requested from LDS before the MFMAs of k-step ku issue
+      Frag ah[2][C::MT], al[2][C::MT];
+      auto load_a = [&](int slot, int ku) {
 #pragma unroll
         for (int mt = 0; mt < C::MT; ++mt) {
           const LT* ap = arow + (size_t)mt * 32 * SA * C::APITCH + ku * C::KS;
+          ah[slot][mt] = *reinterpret_cast<const Frag*>(ap);
+          if constexpr (P::NPL == 2) al[slot][mt] = *reinterpret_cast<const Frag*>(ap + plane);
+        }
+      };
+      load_a(0, 0);
+#pragma unroll
+      for (int ku = 0; ku < KU; ++ku) {
+        if (ku + 1 < KU) load_a((ku + 1) & 1, ku + 1);
+#pragma unroll
+        for (int mt = 0; mt < C::MT; ++mt) {
           if constexpr (P::NPL == 2) {
-            const Frag ah = *reinterpret_cast<const Frag*>(ap);
-            const Frag al = *reinterpret_cast<const Frag*>(ap + plane);
-            acc[v][mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bq[0][ku], acc[v][mt], 0, 0, 0);
-            acc[v][mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bq[1][ku], acc[v][mt], 0, 0, 0);
-            acc[v][mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bq[0][ku], acc[v][mt], 0, 0, 0);
+            acc[v][mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[ku & 1][mt], bq[0][ku], acc[v][mt], 0, 0, 0);
+            acc[v][mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[ku & 1][mt], bq[1][ku], acc[v][mt], 0, 0, 0);
+            acc[v][mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[ku & 1][mt], bq[0][ku], acc[v][mt], 0, 0, 0);
           } else {
-            const Frag af = *reinterpret_cast<const Frag*>(ap);
-            acc[v][mt] = Tr<LT>::mfma(af, bq[0][ku], acc[v][mt]);
+            acc[v][mt] = Tr<LT>::mfma(ah[ku & 1][mt], bq[0][ku], acc[v][mt]);
           }
         }
       }
@@ -229,7 +239,7 @@ __global__ __launch_bounds__(256) void sa_conv_gemm_kernel(SaConvArgs a, int red
       for (int i = 0; i < 16; ++i) {
         const int m = wm * C::MT * 32 + mt * 32 + sa_acc_row(i, lane);
         float val = acc[v][mt][i] + bv;
-        if (a.relu) val = fmaxf(val, 0.0f);
+        if (a.relu & 1) val = fmaxf(val, 0.0f);
         Os[(size_t)(m * U + ph) * C::OPITCH + col] = tr::from_f(val);
       }
     }
@@ -378,6 +388,7 @@ static int launch_tm(const SaConvArgs& a, hipStream_t st) {
   if (cin == CI && cout == CO && sa == S && u == UU)                             \
     return dtype == SA_BF16 ? launch_tm<bf16_t, CI, CO, S, UU>(*a, st)           \
            : dtype == SA_BF16X3 ? launch_tm<bf16x3_t, CI, CO, S, UU>(*a, st)     \
+           : dtype == SA_BF16X1F ? launch_tm<bf16x1f_t, CI, CO, S, UU>(*a, st)   \
                                 : launch_tm<float, CI, CO, S, UU>(*a, st);
 
 // C-ABI entry (see include/sa_hip.h).  Returns 0, or a negative hipError_t / errno.

@@ -73,7 +73,7 @@ extern "C" int sa_pack_weights(int dtype, const float* src, void* dst, int ntaps
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   const int total = ntaps * K * N;
   const int grid = sa_div_up(total, 256) < 1024 ? sa_div_up(total, 256) : 1024;
-  if (dtype == SA_BF16)
+  if (dtype == SA_BF16 || dtype == SA_BF16X1F)
     hipLaunchKernelGGL(sa_pack_weights_kernel<bf16_t>, dim3(grid), dim3(256), 0, s, src,
                        reinterpret_cast<bf16_t*>(dst), ntaps, K, N, sk, sn, st);
   else if (dtype == SA_BF16X3)

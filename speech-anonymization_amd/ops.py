@@ -72,9 +72,9 @@ PROFILE = _Profile()
 
 # precision modes of the MFMA kernels: name -> (activation storage dtype, kernel dtype code)
 PRECISIONS = {"f32": (torch.float32, L.F32), "bf16": (torch.bfloat16, L.BF16),
-              "bf16x3": (torch.float32, L.BF16X3)}
+              "bf16x3": (torch.float32, L.BF16X3), "bf16x1f": (torch.float32, L.BF16X1F)}
 # kernel code of the weight-gradient GEMM per model precision (SA_BF16X1F: see sa_common.h)
-WGRAD_CODE = {"f32": L.F32, "bf16": L.BF16, "bf16x3": L.BF16X1F}
+WGRAD_CODE = {"f32": L.F32, "bf16": L.BF16, "bf16x3": L.BF16X1F, "bf16x1f": L.BF16X1F}
 
 
 def pack_weights(w, kind, dtype, code=None):
@@ -97,6 +97,8 @@ def pack_weights(w, kind, dtype, code=None):
             K, N, sk, sn = Cout, Cin, Kw, Cout * Kw
     if code == L.BF16X3:
         out = torch.empty(2 * Kw * K * N, dtype=torch.bfloat16, device=w.device)
+    elif code == L.BF16X1F:
+        out = torch.empty(Kw * K * N, dtype=torch.bfloat16, device=w.device)
     else:
         out = torch.empty(Kw * K * N, dtype=dtype, device=w.device)
     L.check(lib.sa_pack_weights(code, _f(w), _f(out), Kw, K, N, sk, sn, 1, L.stream()),
