@@ -18,7 +18,23 @@
 //              as a per-tile partial slab (deterministic two-level reduction; no atomics).
 #include "sa_common.h"
 
-#define SA_MAX_HALO 16      // max (largest - smallest) tap row offset the prologue is sized for
+#define SA_MAX_HALO 16
+// -DSA_CONV_STAMPS: diagnostic build (tools/conv_stamps.py) that stamps s_memtime at the phase
+// boundaries of a few workgroups; no stamp exists in the normal build.
+#ifdef SA_CONV_STAMPS
+__device__ unsigned long long sa_conv_dbg[8 * 64];
+#define SA_STAMP_(i, op) do { if (tid == 0 && (blockIdx.x % 97) == 5 && blockIdx.y == 0) { \
+  unsigned long long t_; asm volatile(op " %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); \
+  sa_conv_dbg[(blockIdx.x / 97 % 64) * 8 + (i)] = t_; } } while (0)
+#define SA_STAMP(i) SA_STAMP_(i, "s_memtime")
+#define SA_STAMP_RT(i) SA_STAMP_(i, "s_memrealtime")
+extern "C" int sa_conv_dbg_read(unsigned long long* out) {
+  return -(int)hipMemcpyFromSymbol(out, HIP_SYMBOL(sa_conv_dbg), sizeof(sa_conv_dbg));
+}
+#else
+#define SA_STAMP(i)
+#define SA_STAMP_RT(i)
+#endif      // max (largest - smallest) tap row offset the prologue is sized for
 
 template <typename T, int CIN, int COUT, int SA, int U, int TM>
 struct ConvCfg {
@@ -71,6 +87,7 @@ __global__ __launch_bounds__(256) void sa_conv_gemm_kernel(SaConvArgs a, int red
   const int tile = blockIdx.x, b = blockIdx.y;
   const int m0 = tile * C::BMB;
 
+  SA_STAMP(0);
   // ---------------- prologue: stage + transform the input rows --------------------
   {
     const int c = tid % C::CHI, r0 = tid / C::CHI;
@@ -128,7 +145,9 @@ __global__ __launch_bounds__(256) void sa_conv_gemm_kernel(SaConvArgs a, int red
       }
     }
   }
+  SA_STAMP(1);
   __syncthreads();
+  SA_STAMP(2);
 
   // ---------------- main loop: MFMA over taps x channels -------------------------
   const int wn = wave % C::WN, wm = wave / C::WN;
@@ -205,6 +224,7 @@ __global__ __launch_bounds__(256) void sa_conv_gemm_kernel(SaConvArgs a, int red
       }
     }
   }
+  SA_STAMP(3);
   // fused backward epilogue (ep_mode != 0): the stored forward tensor (and an optional second
   // gradient) of this thread's output chunks are requested now, so the loads fly during the
   // accumulator transpose below
@@ -225,6 +245,7 @@ __global__ __launch_bounds__(256) void sa_conv_gemm_kernel(SaConvArgs a, int red
     }
   }
   __syncthreads();                                   // every wave is done reading As
+  SA_STAMP(4);
 
   // ---------------- epilogue: bias/ReLU -> LDS transpose -> coalesced store ------
 #pragma unroll
@@ -245,6 +266,7 @@ __global__ __launch_bounds__(256) void sa_conv_gemm_kernel(SaConvArgs a, int red
     }
   }
   __syncthreads();
+  SA_STAMP(5);
   {
     const int c = ec, r0 = er0;
     float ssum[OVEC], ssq[OVEC], es1[OVEC], et1[OVEC], emu[OVEC], ers[OVEC];
@@ -303,6 +325,8 @@ __global__ __launch_bounds__(256) void sa_conv_gemm_kernel(SaConvArgs a, int red
       }
     }
   }
+  SA_STAMP(6);
+  SA_STAMP_RT(7);
   if (a.stats) {
     __syncthreads();
     if (tid < COUT) {
