@@ -91,6 +91,9 @@ class ConvAutoencoder(nn.Module):
         )
         self.sex_classifier = TDNNSexClassifier(2)
         self.act_dtype, self.kcode = ops.PRECISIONS[precision]
+        # kernel precision of the decoder convolutions (experiment knob, default = same as the rest)
+        self.dec_kcode = self.kcode
+        self.dgrad_kcode = self.kcode
         # speechbrain's StatisticsPooling adds eps*U[1,9] to the pooled mean on every call
         # (train and eval); True reproduces that, a tensor [B,128] in [0,1] fixes the draw
         # (tests), False/None gives the deterministic form the oracle uses.
@@ -114,6 +117,25 @@ class ConvAutoencoder(nn.Module):
             dist.all_reduce(sums)
             return dist.get_world_size()
         return 1
+
+
+class _W:
+    """packed weight image + the kernel precision code it was packed for"""
+    __slots__ = ("img", "code")
+
+    def __init__(self, img, code):
+        self.img, self.code = img, code
+
+
+def _pack(model, P, key, kind):
+    code = model.dec_kcode if key.startswith("decoder") else model.kcode
+    if kind.endswith("dgrad"):
+        code = model.dgrad_kcode
+    return _W(ops.pack_weights(P[key], kind, model.act_dtype, code), code)
+
+
+def _conv(x, w, *args, **kw):
+    return ops.conv_gemm(x, w.img, *args, code=w.code, **kw)
 
 
 def _noise(model, B, device):
@@ -142,8 +164,8 @@ class _ConvAEFn(torch.autograd.Function):
         L2, L4 = Ltot // 2, Ltot // 4
         S = {}                                                  # saved for backward
         x0 = feats.detach().reshape(B, Ltot).contiguous().float()
-        pw = lambda k, kind: ops.pack_weights(P[k], kind, dt, model.kcode)
-        cg = functools.partial(ops.conv_gemm, code=model.kcode)
+        pw = lambda k, kind: _pack(model, P, k, kind)
+        cg = _conv
 
         def inorm(stats, n, prefix, C):
             sums = ops.sum_partials(stats, B)
@@ -246,8 +268,8 @@ class _ConvAEFn(torch.autograd.Function):
 
         def setg(key, val):
             G[key] = newg(key).copy_(val.reshape(P[key].shape))
-        pw = lambda k, kind: ops.pack_weights(P[k], kind, dt, model.kcode)
-        cg = functools.partial(ops.conv_gemm, code=model.kcode)
+        pw = lambda k, kind: _pack(model, P, k, kind)
+        cg = _conv
         wg = functools.partial(ops.wgrad, code=ops.WGRAD_CODE[model.precision])
 
         def bias_from(stats, key, C):

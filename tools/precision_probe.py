@@ -26,7 +26,15 @@ t0 = time.time()
 o_recon, o_logp, o_loss, o_grads, _ = run_oracle(params, feats, target, gender, "l1")
 print(f"oracle fp32 step: {time.time()-t0:.1f}s  loss {o_loss:.6f}")
 for mode in modes:
-    m = ConvAutoencoder(precision=mode, pooling_noise=None)
+    base, _, dg = mode.partition("+dgrad=")
+    base, _, dec = base.partition("+dec=")
+    m = ConvAutoencoder(precision=base, pooling_noise=None)
+    if dg:
+        from speech_anonymization_amd import ops as _ops
+        m.dgrad_kcode = _ops.PRECISIONS[dg][1]
+    if dec:
+        from speech_anonymization_amd import ops as _ops
+        m.dec_kcode = _ops.PRECISIONS[dec][1]
     m.load_state_dict(params); m.to(dev).train()
     recon, logp, loss, grads = run_hip(m, feats, target, gender, "l1")
     print(f"== {mode}: loss {loss:.6f}  recon {rel_mse(recon, o_recon):.3e}  logp {rel_mse(logp, o_logp):.3e}")
