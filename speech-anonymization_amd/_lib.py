@@ -9,7 +9,8 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libsa_hip.so")
+# SA_HIP_LIB points the binding at another build of the same ABI (kernel A/B experiments)
+LIB_PATH = os.environ.get("SA_HIP_LIB") or os.path.join(_HERE, "libsa_hip.so")
 
 F32, BF16, BF16X3, BF16X1F = 0, 1, 2, 3
 MAX_TAPS = 5

@@ -11,7 +11,7 @@
 // [row][channel] LDS tiles with the gfx950 hardware transpose read ds_read_b64_tr_b16
 // (cdna_hip_programming.md T10); a tap shift is then just a row offset.  The f32 path
 // (v_mfma_f32_32x32x2_f32, one k per lane) reads the same tiles with ds_read_b32.
-// Each workgroup owns one (utterance, row chunk, tap) and writes an fp32 partial slab;
+// Each workgroup owns one (utterance, row chunk) and writes fp32 partial slabs;
 // sa_wgrad_reduce sums the slabs in a fixed order (deterministic) straight into the
 // PyTorch weight layout.
 #include "sa_common.h"
@@ -106,99 +106,102 @@ __device__ static inline bf16x8 sa_tr_frag(const bf16_t* p, int rs) {
   return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
 }
 
-// One workgroup = (utterance b, row chunk, MS x NS channel sub-block) and ALL taps: the
-// (transformed) A rows and the dY rows are staged once per K-tile and reused by every tap (a
-// tap is a row offset into the A tile).  Wave w owns the 32x32 output pair (mt, nt) =
-// (w % NP / NT, w % NP % NT) for all taps (5 accumulators) and, when the sub-block has fewer
-// than 4 pairs, the k-steps ks = w / NP (mod KW).  HBM loads of K-tile i+1 are in flight (in
-// registers) while tile i is in the MFMAs.
+// One workgroup = (utterance b, row chunk), the FULL CIN x COUT block and ALL taps: every A row
+// and dY row is fetched from HBM exactly once (an earlier layout that split the channel block
+// over four workgroups re-read each row twice: 1.32 GB instead of 0.66 GB per 128x128 launch).
+// The (transformed) rows are staged once per K-tile and reused by every tap (a tap is a row
+// offset into the A tile).  The 32x32 output pairs (mt, nt) are dealt over 4 or 8 waves; a
+// wave owns PPW pairs of one mt for all taps (5*PPW accumulators) and, when there are fewer
+// pairs than waves, the k-steps ks = kw (mod KW).  LDS holds two tile buffers: while the
+// MFMAs run on buffer i the rows of K-tile i+1 (loaded one iteration earlier, in registers)
+// are transformed and written to the other buffer and the loads of K-tile i+2 are issued;
+// one barrier per K-tile.  Half of the waves stage first and multiply second, the other half
+// the other way round, so that the VALU and MFMA phases of the two waves on a SIMD overlap.
 template <typename T, int CIN, int COUT, int SA, int U>
 struct WgCfg {
   typedef Pol<T> P;
   typedef typename P::lds_t LT;
-  static constexpr int MS = CIN < 64 ? CIN : 64, NS = COUT < 64 ? COUT : 64;
-  static constexpr int MT = MS / 32, NT = NS / 32, NP = MT * NT, KW = 4 / NP;
+  static constexpr int MT = CIN / 32, NT = COUT / 32, NP = MT * NT;
+  static constexpr int NW = NP >= 8 ? 8 : 4;                       // waves per workgroup
+  static constexpr int NTHR = NW * 64;
+  static constexpr int PPW = NP > NW ? NP / NW : 1;                // pairs per wave (same mt)
+  static constexpr int NPG = NP / PPW;                             // pair groups
+  static constexpr int KW = NW / NPG;                              // k-step split
   static constexpr int KT = (P::NPL == 2 || sizeof(typename P::store_t) == 4) ? 32 : 64;
   static constexpr int HALO = 8;                                   // max tap offset spread
   static constexpr int RA = KT * SA + HALO, RB = KT * U;           // staged rows
-  static constexpr int PA = WgPitch<LT, MS>::value, PB = WgPitch<LT, NS>::value;
-  static constexpr int CHA = MS / P::VEC, CHB = NS / P::VEC;       // 16-byte chunks per row
-  static constexpr int NITA = (RA * CHA + 255) / 256, NITB = (RB * CHB + 255) / 256;
+  static constexpr int PA = WgPitch<LT, CIN>::value, PB = WgPitch<LT, COUT>::value;
+  static constexpr int CHA = CIN / P::VEC, CHB = COUT / P::VEC;    // 16-byte chunks per row
+  static constexpr int NITA = (RA * CHA + NTHR - 1) / NTHR, NITB = (RB * CHB + NTHR - 1) / NTHR;
+  static constexpr int AEL = P::NPL * RA * PA, BEL = P::NPL * RB * PB;     // lds_t elements
+  static constexpr int BUFEL = (AEL + BEL + 7) & ~7;
+  static constexpr size_t LDS = 2 * (size_t)BUFEL * sizeof(LT) + 4 * CIN * sizeof(float);
+  static_assert(NW % NPG == 0 && NT % PPW == 0, "pair dealing");
+  static_assert(NTHR % CHA == 0 && NTHR % CHB == 0, "chunk column must be fixed per thread");
 };
 
 template <typename T, int CIN, int COUT, int SA, int U>
-__global__ __launch_bounds__(256) void sa_wgrad_kernel(SaWgradArgs a) {
+__global__ __launch_bounds__((WgCfg<T, CIN, COUT, SA, U>::NTHR)) void sa_wgrad_kernel(SaWgradArgs a) {
   typedef WgCfg<T, CIN, COUT, SA, U> C;
   typedef Pol<T> P;
   typedef typename P::store_t S;
   typedef typename P::lds_t LT;
   typedef typename P::Frag Frag;
   typedef Tr<S> tr;
-  constexpr int VEC = P::VEC, KS = P::KS, NPL = P::NPL, KT = C::KT;
-  constexpr int PA = C::PA, PB = C::PB;
-  __shared__ __attribute__((aligned(16))) LT At[NPL * C::RA * PA];
-  __shared__ __attribute__((aligned(16))) LT Bt[NPL * C::RB * PB];
+  constexpr int VEC = P::VEC, KS = P::KS, NPL = P::NPL, KT = C::KT, PPW = C::PPW;
+  constexpr int PA = C::PA, PB = C::PB, NTHR = C::NTHR;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  LT* tiles = reinterpret_cast<LT*>(smem);
+  float* coef = reinterpret_cast<float*>(smem + 2 * (size_t)C::BUFEL * sizeof(LT));   // s1 t1 s2 t2
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  // The NSUB channel sub-blocks of one (utterance, row chunk) read the same rows.  Workgroups are
-  // dealt round-robin over the 8 XCDs, so siblings are given linear ids that differ by 8 (same
-  // XCD L2, dispatched close together): id = group*8*NSUB + sub*8 + lane, tile = group*8 + lane.
-  // Pure speed: any placement computes the same slabs.
-  constexpr int NSUB = (CIN / C::MS) * (COUT / C::NS);
-  const int lin = blockIdx.x;
-  const int grp = lin / (8 * NSUB), rem = lin % (8 * NSUB);
-  const int tile = grp * 8 + rem % 8, sub = rem / 8;
-  const int ntile = a.nchunk * a.B;
-  if (tile >= ntile) return;
+  const int tile = blockIdx.x;
   const int chunk = tile % a.nchunk, b = tile / a.nchunk;
-  const int cm0 = (sub / (COUT / C::NS)) * C::MS, cn0 = (sub % (COUT / C::NS)) * C::NS;
   const int mbeg = chunk * a.chunk;
   int mend = mbeg + a.chunk; if (mend > a.Mrows) mend = a.Mrows;
   int offmin = a.off[0];
   for (int t = 1; t < a.ntaps; ++t) offmin = a.off[t] < offmin ? a.off[t] : offmin;
 
-  const int pair = wave % C::NP, kw = wave / C::NP;
-  const int mt = pair / C::NT, nt = pair % C::NT;
-  f32x16 acc[SA_MAX_TAPS];
+  const int grp = wave % C::NPG, kw = wave / C::NPG;
+  const int mt = (grp * PPW) / C::NT, nt0 = (grp * PPW) % C::NT;
+  f32x16 acc[PPW][SA_MAX_TAPS];
 #pragma unroll
-  for (int t = 0; t < SA_MAX_TAPS; ++t)
+  for (int q = 0; q < PPW; ++q)
 #pragma unroll
-    for (int r = 0; r < 16; ++r) acc[t][r] = 0.0f;
+    for (int t = 0; t < SA_MAX_TAPS; ++t)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[q][t][r] = 0.0f;
 
-  // prologue coefficients: 256 % CHA == 0, so a thread stages the same 16-byte channel chunk
-  // in every iteration slot and its coefficients live in registers
-  static_assert(256 % C::CHA == 0 && 256 % C::CHB == 0, "chunk column must be fixed per thread");
+  // prologue coefficients of this utterance: LDS (read back per staged chunk, so that they do
+  // not hold registers across the MFMA phase)
   const bool has1 = a.s1 != nullptr, has2 = a.s2 != nullptr, sw = a.swish != 0;
-  float s1r[VEC], t1r[VEC], s2r[VEC], t2r[VEC];
-#pragma unroll
-  for (int j = 0; j < VEC; ++j) {
-    const int ch = cm0 + (tid % C::CHA) * VEC + j;
-    s1r[j] = has1 ? a.s1[(size_t)b * CIN + ch] : 1.0f;
-    t1r[j] = has1 ? a.t1[(size_t)b * CIN + ch] : 0.0f;
-    s2r[j] = has2 ? a.s2[ch] : 1.0f;
-    t2r[j] = has2 ? a.t2[ch] : 0.0f;
+  for (int ch = tid; ch < CIN; ch += NTHR) {
+    coef[ch] = has1 ? a.s1[(size_t)b * CIN + ch] : 1.0f;
+    coef[CIN + ch] = has1 ? a.t1[(size_t)b * CIN + ch] : 0.0f;
+    coef[2 * CIN + ch] = has2 ? a.s2[ch] : 1.0f;
+    coef[3 * CIN + ch] = has2 ? a.t2[ch] : 0.0f;
   }
-  const S* xb = reinterpret_cast<const S*>(a.x) + (size_t)b * a.Lin * CIN + cm0;
-  const S* yb = reinterpret_cast<const S*>(a.dy) + (size_t)b * a.Ldy * COUT + cn0;
+  const S* xb = reinterpret_cast<const S*>(a.x) + (size_t)b * a.Lin * CIN;
+  const S* yb = reinterpret_cast<const S*>(a.dy) + (size_t)b * a.Ldy * COUT;
   const int dyend = mend * U < a.Ldy ? mend * U : a.Ldy;
+  const int ca = tid % C::CHA, ra0 = tid / C::CHA, cb = tid % C::CHB, rb0 = tid / C::CHB;
+  constexpr int RSA = NTHR / C::CHA, RSB = NTHR / C::CHB;           // row step per iteration slot
 
-  // two register sets: the rows of K-tiles i+1 and i+2 are in flight while tile i is in the MFMAs
-  uint4 rawA0[C::NITA], rawB0[C::NITB], rawA1[C::NITA], rawB1[C::NITB];
-  auto issue = [&](uint4 (&rawA)[C::NITA], uint4 (&rawB)[C::NITB], int m0) {
+  uint4 rawA[C::NITA], rawB[C::NITB];
+  auto issue = [&](int m0) {
 #pragma unroll
     for (int i = 0; i < C::NITA; ++i) {
-      const int e = tid + i * 256, r = e / C::CHA, c = e % C::CHA;
-      const int g = m0 * SA + offmin + r;
+      const int r = ra0 + i * RSA, g = m0 * SA + offmin + r;
       rawA[i] = make_uint4(0, 0, 0, 0);
       if (m0 < mend && r < C::RA && g >= 0 && g < a.Lin)
-        rawA[i] = *reinterpret_cast<const uint4*>(xb + (size_t)g * CIN + c * VEC);
+        rawA[i] = *reinterpret_cast<const uint4*>(xb + (size_t)g * CIN + ca * VEC);
     }
 #pragma unroll
     for (int i = 0; i < C::NITB; ++i) {
-      const int e = tid + i * 256, r = e / C::CHB, c = e % C::CHB;
-      const int g = m0 * U + r;
+      const int r = rb0 + i * RSB, g = m0 * U + r;
       rawB[i] = make_uint4(0, 0, 0, 0);
-      if (m0 < mend && r < C::RB && g < dyend) rawB[i] = *reinterpret_cast<const uint4*>(yb + (size_t)g * COUT + c * VEC);
+      if (m0 < mend && r < C::RB && g < dyend)
+        rawB[i] = *reinterpret_cast<const uint4*>(yb + (size_t)g * COUT + cb * VEC);
     }
   };
   auto put = [&](LT* base, int planes_stride, int pitch, int r, int c, const float* f) {
@@ -214,10 +217,19 @@ __global__ __launch_bounds__(256) void sa_wgrad_kernel(SaWgradArgs a) {
       *reinterpret_cast<uint4*>(dst) = tr::pack(f);
     }
   };
-  auto stage = [&](const uint4 (&rawA)[C::NITA], const uint4 (&rawB)[C::NITB], int m0) {
+  auto stage = [&](LT* At, int m0) {
+    LT* Bt = At + C::AEL;
+    float s1r[VEC], t1r[VEC], s2r[VEC], t2r[VEC];
+    if (has1 || has2) {
+#pragma unroll
+      for (int j = 0; j < VEC; ++j) {
+        s1r[j] = coef[ca * VEC + j]; t1r[j] = coef[CIN + ca * VEC + j];
+        s2r[j] = coef[2 * CIN + ca * VEC + j]; t2r[j] = coef[3 * CIN + ca * VEC + j];
+      }
+    }
 #pragma unroll
     for (int i = 0; i < C::NITA; ++i) {
-      const int e = tid + i * 256, r = e / C::CHA, c = e % C::CHA;
+      const int r = ra0 + i * RSA;
       if (r < C::RA) {
         const int g = m0 * SA + offmin + r;
         float f[VEC];
@@ -232,16 +244,16 @@ __global__ __launch_bounds__(256) void sa_wgrad_kernel(SaWgradArgs a) {
             f[j] = v;
           }
         }
-        put(At, C::RA * PA, PA, r, c, f);
+        put(At, C::RA * PA, PA, r, ca, f);
       }
     }
 #pragma unroll
     for (int i = 0; i < C::NITB; ++i) {
-      const int e = tid + i * 256, r = e / C::CHB, c = e % C::CHB;
+      const int r = rb0 + i * RSB;
       if (r < C::RB) {
         float f[VEC];
         tr::unpack(rawB[i], f);
-        put(Bt, C::RB * PB, PB, r, c, f);
+        put(Bt, C::RB * PB, PB, r, cb, f);
       }
     }
   };
@@ -250,81 +262,98 @@ __global__ __launch_bounds__(256) void sa_wgrad_kernel(SaWgradArgs a) {
   const int trow = 8 * (g4 >> 1) + (i16 >> 2);             // tr-read: k within the 16-deep step
   const int tcol = 16 * (g4 & 1) + 4 * (i16 & 3);          //          column within the 32-wide tile
 
-  auto mfma_tile = [&]() {
+  auto mfma_tile = [&](const LT* At) {
+    const LT* Bt = At + C::AEL;
     for (int ks = kw; ks < KT / KS; ks += C::KW) {
       if constexpr (sizeof(LT) == 2) {
-        Frag bh[U], bl[U];
+        Frag bh[PPW][U], bl[PPW][U];
 #pragma unroll
-        for (int ph = 0; ph < U; ++ph) {
-          const LT* p = Bt + (size_t)((ks * 16 + trow) * U + ph) * PB + nt * 32 + tcol;
-          bh[ph] = sa_tr_frag(p, U * PB);
-          if constexpr (NPL == 2) bl[ph] = sa_tr_frag(p + C::RB * PB, U * PB);
-        }
+        for (int q = 0; q < PPW; ++q)
+#pragma unroll
+          for (int ph = 0; ph < U; ++ph) {
+            const LT* p = Bt + (size_t)((ks * 16 + trow) * U + ph) * PB + (nt0 + q) * 32 + tcol;
+            bh[q][ph] = sa_tr_frag(p, U * PB);
+            if constexpr (NPL == 2) bl[q][ph] = sa_tr_frag(p + C::RB * PB, U * PB);
+          }
 #pragma unroll
         for (int t = 0; t < SA_MAX_TAPS; ++t) {
           if (t < a.ntaps) {
             const LT* p = At + (size_t)((ks * 16 + trow) * SA + a.off[t] - offmin) * PA + mt * 32 + tcol;
             const Frag ah = sa_tr_frag(p, SA * PA);
             const int ph = U == 1 ? 0 : a.ph[t];
-            if constexpr (NPL == 2) {
-              const Frag al = sa_tr_frag(p + C::RA * PA, SA * PA);
-              acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, ph ? bh[U - 1] : bh[0], acc[t], 0, 0, 0);
-              acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, ph ? bl[U - 1] : bl[0], acc[t], 0, 0, 0);
-              acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, ph ? bh[U - 1] : bh[0], acc[t], 0, 0, 0);
-            } else {
-              acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, ph ? bh[U - 1] : bh[0], acc[t], 0, 0, 0);
+            Frag al;
+            if constexpr (NPL == 2) al = sa_tr_frag(p + C::RA * PA, SA * PA);
+#pragma unroll
+            for (int q = 0; q < PPW; ++q) {
+              if constexpr (NPL == 2) {
+                acc[q][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, ph ? bh[q][U - 1] : bh[q][0], acc[q][t], 0, 0, 0);
+                acc[q][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, ph ? bl[q][U - 1] : bl[q][0], acc[q][t], 0, 0, 0);
+              }
+              acc[q][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, ph ? bh[q][U - 1] : bh[q][0], acc[q][t], 0, 0, 0);
             }
           }
         }
       } else {
-        float bv[U];
+        float bv[PPW][U];
 #pragma unroll
-        for (int ph = 0; ph < U; ++ph)
-          bv[ph] = Bt[(size_t)((ks * 2 + (lane >> 5)) * U + ph) * PB + nt * 32 + (lane & 31)];
+        for (int q = 0; q < PPW; ++q)
+#pragma unroll
+          for (int ph = 0; ph < U; ++ph)
+            bv[q][ph] = Bt[(size_t)((ks * 2 + (lane >> 5)) * U + ph) * PB + (nt0 + q) * 32 + (lane & 31)];
 #pragma unroll
         for (int t = 0; t < SA_MAX_TAPS; ++t) {
           if (t < a.ntaps) {
             const float av = At[(size_t)((ks * 2 + (lane >> 5)) * SA + a.off[t] - offmin) * PA + mt * 32 + (lane & 31)];
             const int ph = U == 1 ? 0 : a.ph[t];
-            acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, ph ? bv[U - 1] : bv[0], acc[t], 0, 0, 0);
+#pragma unroll
+            for (int q = 0; q < PPW; ++q)
+              acc[q][t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, ph ? bv[q][U - 1] : bv[q][0], acc[q][t], 0, 0, 0);
           }
         }
       }
     }
   };
-  issue(rawA0, rawB0, mbeg);
-  issue(rawA1, rawB1, mbeg + KT);
-  for (int m0 = mbeg; m0 < mend; m0 += 2 * KT) {
-    stage(rawA0, rawB0, m0);
-    __syncthreads();
-    issue(rawA0, rawB0, m0 + 2 * KT);
-    mfma_tile();
-    __syncthreads();
-    if (m0 + KT < mend) {
-      stage(rawA1, rawB1, m0 + KT);
-      __syncthreads();
-      issue(rawA1, rawB1, m0 + 3 * KT);
-      mfma_tile();
-      __syncthreads();
+
+  issue(mbeg);
+  __syncthreads();                                   // coefficients visible
+  stage(tiles, mbeg);
+  issue(mbeg + KT);
+  __syncthreads();
+  const bool stage_first = wave < C::NW / 2;
+  int cur = 0;
+  for (int m0 = mbeg; m0 < mend; m0 += KT, cur ^= 1) {
+    LT* now = tiles + (size_t)cur * C::BUFEL;
+    LT* nxt = tiles + (size_t)(cur ^ 1) * C::BUFEL;
+    const bool more = m0 + KT < mend;
+    if (stage_first) {
+      if (more) { stage(nxt, m0 + KT); issue(m0 + 2 * KT); }
+      mfma_tile(now);
+    } else {
+      mfma_tile(now);
+      if (more) { stage(nxt, m0 + KT); issue(m0 + 2 * KT); }
     }
+    __syncthreads();
   }
 
-  // ---- fp32 partial slab [kw][tap][CIN][COUT]; this workgroup writes its MS x NS sub-block ----
+  // ---- fp32 partial slab [kw][tap][CIN][COUT] of this (utterance, chunk) ----
   float* slab = a.slabs + ((((size_t)b * a.nchunk + chunk) * C::KW + kw) * a.ntaps) * CIN * COUT;
 #pragma unroll
-  for (int t = 0; t < SA_MAX_TAPS; ++t) {
-    if (t < a.ntaps) {
+  for (int q = 0; q < PPW; ++q)
 #pragma unroll
-      for (int r = 0; r < 16; ++r)
-        slab[((size_t)t * CIN + cm0 + mt * 32 + sa_acc_row(r, lane)) * COUT + cn0 + nt * 32 + (lane & 31)] = acc[t][r];
+    for (int t = 0; t < SA_MAX_TAPS; ++t) {
+      if (t < a.ntaps) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+          slab[((size_t)t * CIN + mt * 32 + sa_acc_row(r, lane)) * COUT + (nt0 + q) * 32 + (lane & 31)] = acc[q][t][r];
+      }
     }
-  }
 }
 
 // slabs per (utterance, chunk): the k-step split factor of the configuration
 extern "C" int sa_wgrad_kw(int cin, int cout) {
-  const int ms = cin < 64 ? cin : 64, ns = cout < 64 ? cout : 64;
-  return 4 / ((ms / 32) * (ns / 32));
+  const int np = (cin / 32) * (cout / 32);
+  const int nw = np >= 8 ? 8 : 4, ppw = np > nw ? np / nw : 1;
+  return nw / (np / ppw);
 }
 
 template <typename T, int CIN, int COUT, int SA, int U>
@@ -337,9 +366,17 @@ static int launch_wgrad(const SaWgradArgs& a, hipStream_t st) {
   }
   if (omax - omin > C::HALO) return -22;
   for (int t = 0; t < a.ntaps; ++t) if (a.ph[t] < 0 || a.ph[t] >= U) return -22;
-  const int nsub = (CIN / C::MS) * (COUT / C::NS);
-  dim3 grid(sa_div_up(a.nchunk * a.B, 8) * 8 * nsub);
-  hipLaunchKernelGGL((sa_wgrad_kernel<T, CIN, COUT, SA, U>), grid, dim3(256), 0, st, a);
+  if (C::LDS > 160 * 1024) return -12;
+  auto kern = sa_wgrad_kernel<T, CIN, COUT, SA, U>;
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e != hipSuccess) return -(int)e;
+    attr_set = true;
+  }
+  dim3 grid(a.nchunk * a.B);
+  hipLaunchKernelGGL(kern, grid, dim3(C::NTHR), C::LDS, st, a);
   hipError_t e = hipGetLastError();
   return e == hipSuccess ? 0 : -(int)e;
 }

@@ -141,8 +141,11 @@ def conv_gemm(x, wp, bias, cin, cout, sa, u, phases, Lout, s1=None, t1=None, s2=
     return (y, stats) if want_stats else y
 
 
+WGRAD_TARGET_WGS = {True: 256, False: 512}
+
+
 def wgrad(x, dy, cin, cout, sa, u, taps, Mrows, dst, dst_strides, s1=None, t1=None, s2=None,
-          t2=None, swish=False, accumulate=False, target_wgs=1024, code=None):
+          t2=None, swish=False, accumulate=False, target_wgs=None, code=None):
     """taps: list of (row_offset, phase) per weight tap.  dst: fp32 parameter-gradient tensor in
     PyTorch layout; dst_strides = (s_ci, s_co, s_tap)."""
     lib = L.load()
@@ -150,8 +153,11 @@ def wgrad(x, dy, cin, cout, sa, u, taps, Mrows, dst, dst_strides, s1=None, t1=No
     Ldy = dy.shape[1]
     nt = len(taps)
     kw = lib.sa_wgrad_kw(cin, cout)
-    nsub = (cin // min(cin, 64)) * (cout // min(cout, 64))
-    chunk = max(64, -(-Mrows * nsub * B // target_wgs))
+    if target_wgs is None:
+        # one 8-wave workgroup (128-wide channel blocks) or two-three 4-wave ones fit a CU: size
+        # the row chunks so that the grid is one resident wave of workgroups over the 256 CUs
+        target_wgs = WGRAD_TARGET_WGS[(cin // 32) * (cout // 32) >= 8]
+    chunk = max(64, -(-Mrows * B // target_wgs))
     chunk = -(-chunk // 64) * 64
     nchunk = -(-Mrows // chunk)
     slabs = torch.empty(B * nchunk * kw * nt * cin * cout, dtype=torch.float32, device=x.device)

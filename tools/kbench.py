@@ -6,6 +6,9 @@ import torch
 from speech_anonymization_amd import ops
 
 dev = torch.device("cuda:0")
+if os.environ.get("KB_WG_TARGET"):                     # "big,small" workgroup-count targets of ops.wgrad
+    _b, _s = os.environ["KB_WG_TARGET"].split(",")
+    ops.WGRAD_TARGET_WGS.update({True: int(_b), False: int(_s)})
 what = (sys.argv[1] if len(sys.argv) > 1 else "all") if __name__ == "__main__" else "none"
 precs = (sys.argv[2] if len(sys.argv) > 2 else "bf16x3,bf16,f32").split(",")
 B, L4 = int(__import__("os").environ.get("KB_B", "10")), 20160
@@ -60,8 +63,12 @@ for prec in precs:
                 taps, Mrows, dst, strides = [(1, 0), (1, 1), (0, 0), (0, 1), (-1, 0)], Lin, torch.empty(cin, cout, 5, device=dev), (cout * 5, 5, 1)
             else:
                 taps, Mrows, dst, strides = [(k - 2, 0) for k in range(5)], Lout, torch.empty(cout, cin, 5, device=dev), (5, cin * 5, 1)
-            f = lambda: ops.wgrad(x, dy, cin, cout, sa, u, taps, Mrows, dst, strides, s1=s1, t1=t1,
-                                  swish=True, code=ops.WGRAD_CODE[prec])
+            if os.environ.get("KB_WG_RAW"):                 # no prologue transform (VALU share probe)
+                f = lambda: ops.wgrad(x, dy, cin, cout, sa, u, taps, Mrows, dst, strides,
+                                      code=ops.WGRAD_CODE[prec])
+            else:
+                f = lambda: ops.wgrad(x, dy, cin, cout, sa, u, taps, Mrows, dst, strides, s1=s1, t1=t1,
+                                      swish=True, code=ops.WGRAD_CODE[prec])
             us = timeit(f)
             flops = 2 * B * Mrows * 5 * cin * cout
             byts = (x.numel() + dy.numel()) * x.element_size()
