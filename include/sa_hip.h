@@ -78,10 +78,18 @@ int sa_conv_gemm_set_tile_rows(int rows);   /* tuning knob: 0 (default policy), 
 int sa_pack_weights(int dtype, const float* src, void* dst, int ntaps, int K, int N, int sk, int sn,
                     int st, void* stream);
 
+/* n images in one launch: descs is an array of n records in DEVICE memory (the record of image i
+ * holds the arguments sa_pack_weights would take for it). */
+typedef struct SaPackDesc {
+  const float* src; void* dst;
+  int dtype, ntaps, K, N, sk, sn, st, pad_;
+} SaPackDesc;
+int sa_pack_weights_multi(const SaPackDesc* descs, int n, int blocks_per_image, void* stream);
+
 /* ---- weight gradients (sa_wgrad.hip) --------------------------------------------------
  * dW[t][ci][co] = sum_b sum_{m<Mrows} P(x)[b, m*SA+off[t], ci] * dy[b, m*U+ph[t], co];
- * grid (nchunk, channel sub-blocks, B): each workgroup covers `chunk` (multiple of 64) base rows,
- * every tap, and one (<=64 x <=64) channel sub-block; slabs[b][chunk][kw][t][CIN][COUT] with
+ * grid nchunk*B: each workgroup covers `chunk` (multiple of 64) base rows, every tap and the
+ * whole CIN x COUT block; slabs[b][chunk][kw][t][CIN][COUT] with
  * kw < sa_wgrad_kw(cin, cout); sa_wgrad_reduce sums the B*nchunk*kw slabs in a fixed order into
  * dst[ci*sk + co*sn + t*st]. */
 typedef struct SaWgradArgs {

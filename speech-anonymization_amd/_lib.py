@@ -34,6 +34,11 @@ class SaConvArgs(C.Structure):
                 ("ep_x", vp), ("ep_g2", vp), ("ep_s1", vp), ("ep_t1", vp), ("ep_mean", vp), ("ep_rstd", vp)]
 
 
+class SaPackDesc(C.Structure):
+    _fields_ = [("src", vp), ("dst", vp), ("dtype", C.c_int), ("ntaps", C.c_int), ("K", C.c_int),
+                ("N", C.c_int), ("sk", C.c_int), ("sn", C.c_int), ("st", C.c_int), ("pad_", C.c_int)]
+
+
 class SaWgradArgs(C.Structure):
     _fields_ = [("x", vp), ("dy", vp), ("slabs", vp),
                 ("s1", vp), ("t1", vp), ("s2", vp), ("t2", vp), ("swish", C.c_int),
@@ -53,7 +58,7 @@ class SaEwArgs(C.Structure):
 
 # every symbol include/sa_hip.h declares (checked by tests/test_abi.py on CPU)
 SYMBOLS = [
-    "sa_conv_gemm", "sa_conv_gemm_ntiles", "sa_conv_gemm_set_tile_rows", "sa_pack_weights", "sa_wgrad", "sa_wgrad_kw", "sa_wgrad_reduce",
+    "sa_conv_gemm", "sa_conv_gemm_ntiles", "sa_conv_gemm_set_tile_rows", "sa_pack_weights", "sa_pack_weights_multi", "sa_wgrad", "sa_wgrad_kw", "sa_wgrad_reduce",
     "sa_conv1toC", "sa_conv1toC_ntiles", "sa_convCto1", "sa_wgrad1C", "sa_wgrad1C_nchunk",
     "sa_sum_slabs", "sa_ew_stats", "sa_ew_apply", "sa_ew_ntiles", "sa_act_stats",
     "sa_sum_partials", "sa_sum_rows_d", "sa_fin_in_fwd", "sa_fin_bn_fwd", "sa_fin_bn_eval", "sa_fin_norm_bwd", "sa_fin_bias",

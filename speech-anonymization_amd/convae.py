@@ -127,11 +127,39 @@ class _W:
         self.img, self.code = img, code
 
 
-def _pack(model, P, key, kind):
-    code = model.dec_kcode if key.startswith("decoder") else model.kcode
+# every (weight, use) pair the fused forward / backward multiplies with
+PACK_PLAN = (
+    [(k, "conv_fwd") for k in ("encoder.2.weight", "encoder.5.weight", "encoder.8.weight",
+                               "encoder.11.weight", "sex_classifier.tdnn.0.weight",
+                               "sex_classifier.tdnn.3.weight", "sex_classifier.tdnn.6.weight",
+                               "decoder.0.weight", "decoder.4.weight")]
+    + [(k, "convT_fwd") for k in ("decoder.1.weight", "decoder.5.weight")]
+    + [(k, "conv_dgrad") for k in ("encoder.2.weight", "encoder.5.weight", "encoder.8.weight",
+                                   "encoder.11.weight", "sex_classifier.tdnn.0.weight",
+                                   "sex_classifier.tdnn.3.weight", "sex_classifier.tdnn.6.weight",
+                                   "decoder.0.weight", "decoder.4.weight")]
+    + [(k, "convT_dgrad") for k in ("decoder.1.weight", "decoder.5.weight")])
+
+
+def _kcode(model, key, kind):
     if kind.endswith("dgrad"):
-        code = model.dgrad_kcode
-    return _W(ops.pack_weights(P[key], kind, model.act_dtype, code), code)
+        return model.dgrad_kcode
+    return model.dec_kcode if key.startswith("decoder") else model.kcode
+
+
+def _packed(model, P):
+    """All operand images of the current weights, refreshed by ONE launch.  The image buffers
+    are persistent (keyed by the parameters' storage): a backward uses the images its forward
+    packed, which is what autograd's saved-tensor semantics ask for as long as the weights are
+    not modified between the two."""
+    items = [((k, kind), P[k], kind, _kcode(model, k, kind)) for k, kind in PACK_PLAN]
+    key = tuple(w.data_ptr() for _, w, _, _ in items) + tuple(c for _, _, _, c in items)
+    pk = getattr(model, "_pack_cache", None)
+    if pk is None or pk[0] != key:
+        pk = (key, ops.PackedWeights(items, model.act_dtype))
+        model._pack_cache = pk
+    pk[1].refresh()
+    return {tag: _W(img, code) for tag, (img, code) in pk[1].images.items()}
 
 
 def _conv(x, w, *args, **kw):
@@ -164,7 +192,8 @@ class _ConvAEFn(torch.autograd.Function):
         L2, L4 = Ltot // 2, Ltot // 4
         S = {}                                                  # saved for backward
         x0 = feats.detach().reshape(B, Ltot).contiguous().float()
-        pw = lambda k, kind: _pack(model, P, k, kind)
+        W = _packed(model, P)
+        pw = lambda k, kind: W[(k, kind)]
         cg = _conv
 
         def inorm(stats, n, prefix, C):
@@ -240,7 +269,7 @@ class _ConvAEFn(torch.autograd.Function):
         S.update(x0=x0, y=[y0, y1, y2, y3, y4, y5, y6, y7, y8], r=[r0, r1, r2],
                  n=[None, n1, n2, n3, n4, None, n6, None, n8], bn=[bn_n, bn0, bn1, bn2], f=[f1, f2],
                  pooled=pooled, pmean=pmean, psd=psd, H1=H1, H2=H2, logp=logp,
-                 dims=(B, T, Ltot, L2, L4, La, Lb, Lc), train=train)
+                 dims=(B, T, Ltot, L2, L4, La, Lb, Lc), train=train, W=W)
         ctx.S, ctx.model, ctx.names, ctx.params = S, model, names, params
         ctx.need_input_grad = feats.requires_grad
         return recon.view(B, T, Fd), logp
@@ -268,7 +297,8 @@ class _ConvAEFn(torch.autograd.Function):
 
         def setg(key, val):
             G[key] = newg(key).copy_(val.reshape(P[key].shape))
-        pw = lambda k, kind: _pack(model, P, k, kind)
+        W = S["W"]
+        pw = lambda k, kind: W[(k, kind)]
         cg = _conv
         wg = functools.partial(ops.wgrad, code=ops.WGRAD_CODE[model.precision])
 
@@ -381,7 +411,7 @@ class _ConvAEFn(torch.autograd.Function):
         # ======================= decoder =======================
         g_rec = d_recon.reshape(B, Ltot).contiguous().float()
         if need["decoder.8.bias"]:
-            setg("decoder.8.bias", ops.sum_partials(g_rec, 1, n=80).sum())
+            setg("decoder.8.bias", ops.sum_partials(g_rec.view(4 * B, Ltot // 4), 1, n=Ltot // 4).sum())
         if need["decoder.8.weight"]:
             G["decoder.8.weight"] = ops.wgrad1C(g_rec, y8, newg("decoder.8.weight"), flip=True,
                                                 s1=n8[2], t1=n8[3], swish=True)

@@ -227,6 +227,7 @@ __global__ void sa_sum_rows_d_kernel(const double* __restrict__ src, double* __r
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   double s = 0.0;
+#pragma unroll 8
   for (int r = 0; r < R; ++r) s += src[(size_t)r * n + i];
   dst[i] = s;
 }
@@ -365,6 +366,7 @@ __global__ void sa_fin_bias_kernel(const double* __restrict__ sums, int B, int C
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= C) return;
   double s = 0.0;
+#pragma unroll 8
   for (int b = 0; b < B; ++b) s += sums[2 * ((size_t)b * C + i)];
   db[i] = (float)s;
 }

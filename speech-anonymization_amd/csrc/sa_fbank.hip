@@ -165,27 +165,37 @@ __global__ __launch_bounds__(256) void sa_fbank_utt_partial_kernel(const float* 
 // InputNormalization "global": per-utterance mean / unbiased std (floored at 1e-10) from the
 // chunk partials, averaged over the batch, folded into the running state
 // [count, glob_mean[80], glob_std[80]] (speechbrain semantics restated in oracle/features.py).
-__global__ void sa_norm_update_kernel(const double* __restrict__ part, const float* __restrict__ lens,
-                                      int B, int T, int update, int epoch, int update_until_epoch,
-                                      float* state) {
-  const int f = threadIdx.x;
+// 80 features x 8 utterance lanes: lane q handles utterances q, q+8, ... (all loads of one
+// utterance are independent), the 8 lane sums are added in lane order by the q = 0 thread.
+__global__ __launch_bounds__(640) void sa_norm_update_kernel(const double* __restrict__ part,
+                                                             const float* __restrict__ lens, int B, int T,
+                                                             int update, int epoch, int update_until_epoch,
+                                                             float* state) {
+  __shared__ float lm[8][SA_NMEL], ls[8][SA_NMEL];
+  const int f = threadIdx.x % SA_NMEL, q = threadIdx.x / SA_NMEL;
   const float count = state[0];
-  if (f < SA_NMEL) {
-    float cm = 0.f, cs = 0.f;
-    for (int b = 0; b < B; ++b) {
-      int n = (int)rintf(lens[b] * (float)T);
-      if (n > T) n = T;
-      double s = 0.0, q = 0.0;
-      for (int c = 0; c < SA_UTT_CHUNKS; ++c) {
-        const double* d = part + (((size_t)b * SA_UTT_CHUNKS + c) * SA_NMEL + f) * 2;
-        s += d[0]; q += d[1];
-      }
-      const double m = s / n;
-      double var = n > 1 ? (q - s * m) / (n - 1) : 0.0;
-      if (var < 0.0) var = 0.0;
-      cm += (float)m;
-      cs += fmaxf((float)sqrt(var), 1e-10f);
+  float cm = 0.f, cs = 0.f;
+  for (int b = q; b < B; b += 8) {
+    int n = (int)rintf(lens[b] * (float)T);
+    if (n > T) n = T;
+    double s = 0.0, sq = 0.0;
+#pragma unroll
+    for (int c = 0; c < SA_UTT_CHUNKS; ++c) {
+      const double* d = part + (((size_t)b * SA_UTT_CHUNKS + c) * SA_NMEL + f) * 2;
+      s += d[0]; sq += d[1];
     }
+    const double m = s / n;
+    double var = n > 1 ? (sq - s * m) / (n - 1) : 0.0;
+    if (var < 0.0) var = 0.0;
+    cm += (float)m;
+    cs += fmaxf((float)sqrt(var), 1e-10f);
+  }
+  lm[q][f] = cm; ls[q][f] = cs;
+  __syncthreads();
+  if (q == 0) {
+    cm = 0.f; cs = 0.f;
+#pragma unroll
+    for (int r = 0; r < 8; ++r) { cm += lm[r][f]; cs += ls[r][f]; }
     cm /= B; cs /= B;
     if (update) {
       if (count == 0.0f) { state[1 + f] = cm; state[1 + SA_NMEL + f] = cs; }
@@ -197,7 +207,7 @@ __global__ void sa_norm_update_kernel(const double* __restrict__ part, const flo
     }
   }
   __syncthreads();
-  if (f == 0 && update) state[0] = count + 1.0f;
+  if (threadIdx.x == 0 && update) state[0] = count + 1.0f;
 }
 
 // out[b][t][f] = (max(feats, floor[b]) - glob_mean[f]) / glob_std[f] for t < T, 0 for T <= t < Tp
@@ -238,7 +248,7 @@ extern "C" int sa_fbank_normalize(const float* feats, const float* tilemax, int 
   double* part = reinterpret_cast<double*>(scratch + ((B + 1) & ~1));
   hipLaunchKernelGGL(sa_fbank_utt_partial_kernel, dim3(SA_UTT_CHUNKS, B), dim3(256), 0, st, feats,
                      tilemax, sa_div_up(T, SA_FB_FRAMES), B, T, lens, top_db, batch_max, fl, part);
-  hipLaunchKernelGGL(sa_norm_update_kernel, dim3(1), dim3(128), 0, st, part, lens, B, T, update, epoch,
+  hipLaunchKernelGGL(sa_norm_update_kernel, dim3(1), dim3(640), 0, st, part, lens, B, T, update, epoch,
                      update_until_epoch, state);
   const size_t n4 = (size_t)Tp * SA_NMEL / 4;
   hipLaunchKernelGGL(sa_norm_apply_kernel, dim3((unsigned)((n4 + 255) / 256), B), dim3(256), 0, st,

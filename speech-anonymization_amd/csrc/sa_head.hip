@@ -372,10 +372,19 @@ __global__ __launch_bounds__(256) void sa_recon_loss_kernel(const float* __restr
   __syncthreads();
   if (threadIdx.x == 0) part[blockIdx.x] = wsum[0] + wsum[1] + wsum[2] + wsum[3];
 }
+// 64 threads: thread i adds partials i, i+64, ... in order, thread 0 adds the 64 lane sums in order
 __global__ void sa_recon_loss_fin_kernel(const double* part, int nb, double n, float* loss) {
+  __shared__ double lane_sum[64];
   double s = 0.0;
-  for (int i = 0; i < nb; ++i) s += part[i];
-  loss[0] = (float)(s / n);
+#pragma unroll 8
+  for (int i = threadIdx.x; i < nb; i += 64) s += part[i];
+  lane_sum[threadIdx.x] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double t = 0.0;
+    for (int i = 0; i < 64; ++i) t += lane_sum[i];
+    loss[0] = (float)(t / n);
+  }
 }
 #define SA_LOSS_BLOCKS 512
 extern "C" int sa_loss_workspace_bytes() { return SA_LOSS_BLOCKS * (int)sizeof(double); }
@@ -390,7 +399,7 @@ extern "C" int sa_recon_loss(const float* a, const float* b, long long n, int ki
   if (nb > SA_LOSS_BLOCKS) nb = SA_LOSS_BLOCKS;
   hipLaunchKernelGGL(sa_recon_loss_kernel, dim3(nb), dim3(256), 0, st, a, b, (size_t)n, kind, grad,
                      reinterpret_cast<double*>(workspace));
-  hipLaunchKernelGGL(sa_recon_loss_fin_kernel, dim3(1), dim3(1), 0, st,
+  hipLaunchKernelGGL(sa_recon_loss_fin_kernel, dim3(1), dim3(64), 0, st,
                      reinterpret_cast<const double*>(workspace), nb, (double)n, loss);
   hipError_t e = hipGetLastError();
   return e == hipSuccess ? 0 : -(int)e;

@@ -86,6 +86,44 @@ extern "C" int sa_pack_weights(int dtype, const float* src, void* dst, int ntaps
   return e == hipSuccess ? 0 : -(int)e;
 }
 
+// All weight images of a model in one launch: descs (device memory) holds n SaPackDesc records,
+// workgroup column y packs image y with the same element mapping as sa_pack_weights.
+__global__ void sa_pack_weights_multi_kernel(const SaPackDesc* __restrict__ descs) {
+  const SaPackDesc d = descs[blockIdx.y];
+  const bool f32 = d.dtype == SA_F32, split = d.dtype == SA_BF16X3;
+  const int KS = f32 ? 2 : 16, PER = KS / 2;
+  const int total = d.ntaps * d.K * d.N;
+  const int NT = d.N / 32, KSTEPS = d.K / KS;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+    const int j = i % PER;
+    int r = i / PER;
+    const int lane = r % 64; r /= 64;
+    const int nt = r % NT; r /= NT;
+    const int ks = r % KSTEPS;
+    const int t = r / KSTEPS;
+    const int k = ks * KS + PER * (lane >> 5) + j;
+    const int n = nt * 32 + (lane & 31);
+    const float w = d.src[(size_t)k * d.sk + (size_t)n * d.sn + (size_t)t * d.st];
+    if (f32) {
+      reinterpret_cast<float*>(d.dst)[i] = w;
+    } else {
+      bf16_t* o = reinterpret_cast<bf16_t*>(d.dst);
+      const bf16_t hi = (bf16_t)w;
+      o[i] = hi;
+      if (split) o[(size_t)total + i] = (bf16_t)(w - (float)hi);
+    }
+  }
+}
+
+extern "C" int sa_pack_weights_multi(const SaPackDesc* descs, int n, int blocks_per_image,
+                                     void* stream) {
+  if (!descs || n <= 0 || blocks_per_image <= 0) return -22;
+  hipLaunchKernelGGL(sa_pack_weights_multi_kernel, dim3(blocks_per_image, n), dim3(256), 0,
+                     reinterpret_cast<hipStream_t>(stream), descs);
+  hipError_t e = hipGetLastError();
+  return e == hipSuccess ? 0 : -(int)e;
+}
+
 // ---------------------------------------------------------------------------------
 // wgrad GEMM
 // ---------------------------------------------------------------------------------

@@ -77,33 +77,62 @@ PRECISIONS = {"f32": (torch.float32, L.F32), "bf16": (torch.bfloat16, L.BF16),
 WGRAD_CODE = {"f32": L.F32, "bf16": L.BF16, "bf16x3": L.BF16X1F, "bf16x1f": L.BF16X1F}
 
 
+def _pack_geometry(shape, kind):
+    """(Kw, K, N, sk, sn) of sa_pack_weights for a parameter of `shape` used as `kind`."""
+    if kind in ("conv_fwd", "conv_dgrad"):
+        Cout, Cin, Kw = shape
+        if kind == "conv_fwd":
+            return Kw, Cin, Cout, Kw, Cin * Kw
+        return Kw, Cout, Cin, Cin * Kw, Kw
+    Cin, Cout, Kw = shape
+    if kind == "convT_fwd":
+        return Kw, Cin, Cout, Cout * Kw, Kw
+    return Kw, Cout, Cin, Kw, Cout * Kw
+
+
+def _image_buffer(code, dtype, n, device):
+    if code == L.BF16X3:
+        return torch.empty(2 * n, dtype=torch.bfloat16, device=device)
+    if code in (L.BF16X1F, L.BF16):
+        return torch.empty(n, dtype=torch.bfloat16, device=device)
+    return torch.empty(n, dtype=torch.float32, device=device)
+
+
 def pack_weights(w, kind, dtype, code=None):
     """w: fp32 parameter in PyTorch layout.  kind: conv_fwd | conv_dgrad | convT_fwd |
     convT_dgrad.  Returns the fragment-major operand image (flat tensor; for code BF16X3 the
     hi image followed by the lo image, both bf16)."""
     lib = L.load()
     code = L.dt_code(dtype) if code is None else code
-    if kind in ("conv_fwd", "conv_dgrad"):
-        Cout, Cin, Kw = w.shape
-        if kind == "conv_fwd":
-            K, N, sk, sn = Cin, Cout, Kw, Cin * Kw
-        else:
-            K, N, sk, sn = Cout, Cin, Cin * Kw, Kw
-    else:
-        Cin, Cout, Kw = w.shape
-        if kind == "convT_fwd":
-            K, N, sk, sn = Cin, Cout, Cout * Kw, Kw
-        else:
-            K, N, sk, sn = Cout, Cin, Kw, Cout * Kw
-    if code == L.BF16X3:
-        out = torch.empty(2 * Kw * K * N, dtype=torch.bfloat16, device=w.device)
-    elif code == L.BF16X1F:
-        out = torch.empty(Kw * K * N, dtype=torch.bfloat16, device=w.device)
-    else:
-        out = torch.empty(Kw * K * N, dtype=dtype, device=w.device)
+    Kw, K, N, sk, sn = _pack_geometry(w.shape, kind)
+    out = _image_buffer(code, dtype, Kw * K * N, w.device)
     L.check(lib.sa_pack_weights(code, _f(w), _f(out), Kw, K, N, sk, sn, 1, L.stream()),
             "sa_pack_weights")
     return out
+
+
+class PackedWeights:
+    """Persistent operand images of a fixed list of (parameter, kind, code) and the device-side
+    descriptor table that lets one sa_pack_weights_multi launch refresh all of them."""
+
+    def __init__(self, items, dtype):
+        """items: list of (tag, fp32 parameter tensor, kind, code)."""
+        self.images, descs = {}, (L.SaPackDesc * len(items))()
+        dev = items[0][1].device
+        for d, (tag, w, kind, code) in zip(descs, items):
+            Kw, K, N, sk, sn = _pack_geometry(w.shape, kind)
+            img = _image_buffer(code, dtype, Kw * K * N, dev)
+            self.images[tag] = (img, code)
+            d.src, d.dst, d.dtype = w.data_ptr(), img.data_ptr(), code
+            d.ntaps, d.K, d.N, d.sk, d.sn, d.st = Kw, K, N, sk, sn, 1
+        raw = torch.frombuffer(bytearray(bytes(descs)), dtype=torch.uint8)
+        self.table = raw.to(dev)
+        self.n = len(items)
+        self.key = tuple(w.data_ptr() for _, w, _, _ in items)
+
+    def refresh(self):
+        L.check(L.load().sa_pack_weights_multi(_f(self.table), self.n, 64, L.stream()),
+                "sa_pack_weights_multi")
 
 
 def conv_gemm(x, wp, bias, cin, cout, sa, u, phases, Lout, s1=None, t1=None, s2=None, t2=None,

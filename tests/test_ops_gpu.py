@@ -438,3 +438,28 @@ def test_xvector_classifier_forward():
     enc = HX.EncoderClassifier(hx, hc)
     out, score, index = enc.classify_batch_feats(feats.to(dev()), lens)
     assert out.shape == (B, 2) and index.shape == (B,)
+
+
+def test_pack_weights_multi_matches_single():
+    """one-launch refresh of several images == sa_pack_weights image by image (all codes/kinds)."""
+    from speech_anonymization_amd import _lib as L, ops
+    dev = torch.device("cuda:0")
+    g = torch.Generator(device="cpu").manual_seed(3)
+    items = []
+    for i, (shape, kind, code, dt) in enumerate([
+            ((128, 64, 5), "conv_fwd", L.BF16X3, torch.float32),
+            ((128, 128, 3), "conv_dgrad", L.BF16X3, torch.float32),
+            ((128, 64, 5), "convT_fwd", L.BF16X1F, torch.float32),
+            ((64, 32, 5), "convT_dgrad", L.F32, torch.float32),
+            ((64, 64, 5), "conv_fwd", L.BF16, torch.float32)]):
+        w = torch.randn(*shape, generator=g).to(dev)
+        items.append((i, w, kind, code))
+    pk = ops.PackedWeights(items, torch.float32)
+    for img, _ in pk.images.values():
+        img.zero_()
+    pk.refresh()
+    for tag, w, kind, code in items:
+        img, c = pk.images[tag]
+        one = ops.pack_weights(w, kind, torch.bfloat16 if code == L.BF16 else torch.float32, code)
+        assert c == code and img.numel() == one.numel()
+        assert torch.equal(img.view(torch.uint8), one.view(torch.uint8))
