@@ -65,6 +65,9 @@ typedef struct SaConvArgs {
   int ep_mode, ep_xp_is_act, ep_bstride;
   const void* ep_x; const void* ep_g2;
   const float* ep_s1; const float* ep_t1; const float* ep_mean; const float* ep_rstd;
+  /* optional second output: the transformed input rows P(x) = s2*act(s1*x+t1)+t2, rounded to bf16,
+   * [B][Lin][CIN] -- what sa_wgrad multiplies with when SaWgradArgs.x_pre is set */
+  void* a_out;
 } SaConvArgs;
 
 int sa_conv_gemm(int dtype, int cin, int cout, int sa, int u, const SaConvArgs* a, void* stream);
@@ -99,6 +102,8 @@ typedef struct SaWgradArgs {
   const float* s1; const float* t1; const float* s2; const float* t2; int swish;
   int B, Lin, Ldy, Mrows, chunk, nchunk;
   int ntaps; int off[SA_MAX_TAPS]; int ph[SA_MAX_TAPS];
+  int x_pre;   /* x is SaConvArgs.a_out of the forward launch (bf16, already transformed; s1..swish
+                * ignored).  SA_BF16X1F only. */
 } SaWgradArgs;
 
 int sa_wgrad(int dtype, int cin, int cout, int sa, int u, const SaWgradArgs* a, void* stream);

@@ -31,7 +31,8 @@ class SaConvArgs(C.Structure):
                 ("B", C.c_int), ("Lin", C.c_int), ("Lout", C.c_int), ("ntiles", C.c_int),
                 ("rowmin", C.c_int), ("nrows", C.c_int), ("wlo_off", C.c_int), ("taps", SaTaps),
                 ("ep_mode", C.c_int), ("ep_xp_is_act", C.c_int), ("ep_bstride", C.c_int),
-                ("ep_x", vp), ("ep_g2", vp), ("ep_s1", vp), ("ep_t1", vp), ("ep_mean", vp), ("ep_rstd", vp)]
+                ("ep_x", vp), ("ep_g2", vp), ("ep_s1", vp), ("ep_t1", vp), ("ep_mean", vp), ("ep_rstd", vp),
+                ("a_out", vp)]
 
 
 class SaPackDesc(C.Structure):
@@ -44,7 +45,8 @@ class SaWgradArgs(C.Structure):
                 ("s1", vp), ("t1", vp), ("s2", vp), ("t2", vp), ("swish", C.c_int),
                 ("B", C.c_int), ("Lin", C.c_int), ("Ldy", C.c_int), ("Mrows", C.c_int),
                 ("chunk", C.c_int), ("nchunk", C.c_int),
-                ("ntaps", C.c_int), ("off", C.c_int * MAX_TAPS), ("ph", C.c_int * MAX_TAPS)]
+                ("ntaps", C.c_int), ("off", C.c_int * MAX_TAPS), ("ph", C.c_int * MAX_TAPS),
+                ("x_pre", C.c_int)]
 
 
 class SaEwArgs(C.Structure):

@@ -20,6 +20,7 @@ import torch.nn as nn
 
 from . import distributed as sdist
 from . import ops
+from . import _lib as L
 from ._lib import SaHipError
 
 K5 = 5
@@ -62,11 +63,13 @@ class TDNNSexClassifier(nn.Module):
 
 
 class ConvAutoencoder(nn.Module):
-    def __init__(self, precision="bf16x3", pooling_noise=True, sync_bn=True, dtype=None):
+    def __init__(self, precision="bf16x3", pooling_noise=True, sync_bn=True, dtype=None,
+                 cache_wgrad_operand=True):
         """precision: "bf16x3" (default: fp32 storage, split-bf16 operands on the bf16 MFMA --
         meets the 1e-4 parity bar), "bf16" (bf16 storage + single bf16 MFMA: fastest, ~2e-4 on
         recon), "f32" (exact fp32 MFMA).  dtype=torch.float32 / torch.bfloat16 selects "f32" /
-        "bf16" (kept for callers that think in torch dtypes)."""
+        "bf16" (kept for callers that think in torch dtypes).  cache_wgrad_operand=False trades
+        the bf16 operand cache (memory) for recomputation in the weight-gradient kernels."""
         super().__init__()
         if dtype is not None:
             precision = {torch.float32: "f32", torch.bfloat16: "bf16"}[dtype]
@@ -94,6 +97,9 @@ class ConvAutoencoder(nn.Module):
         # kernel precision of the decoder convolutions (experiment knob, default = same as the rest)
         self.dec_kcode = self.kcode
         self.dgrad_kcode = self.kcode
+        # forward convs also store their transformed input in bf16 for the weight gradient
+        # (bf16x3 / bf16x1f models; +1/2 of the saved activations in memory, identical results)
+        self.cache_wgrad_operand = cache_wgrad_operand
         # speechbrain's StatisticsPooling adds eps*U[1,9] to the pooled mean on every call
         # (train and eval); True reproduces that, a tensor [B,128] in [0,1] fixes the draw
         # (tests), False/None gives the deterministic form the oracle uses.
@@ -194,7 +200,15 @@ class _ConvAEFn(torch.autograd.Function):
         x0 = feats.detach().reshape(B, Ltot).contiguous().float()
         W = _packed(model, P)
         pw = lambda k, kind: W[(k, kind)]
-        cg = _conv
+        # activation cache: each conv also writes its transformed input rows in bf16, the operand
+        # its weight gradient multiplies with (saves the recomputation and half of the bytes there)
+        A = {}
+        cache_a = train and model.cache_wgrad_operand and ops.WGRAD_CODE[model.precision] == L.BF16X1F
+
+        def cg(x, w, key, *args, **kw):
+            if cache_a and key is not None and P[key].requires_grad:
+                A[key] = kw["a_out"] = torch.empty(x.shape, dtype=torch.bfloat16, device=x.device)
+            return _conv(x, w, *args, **kw)
 
         def inorm(stats, n, prefix, C):
             sums = ops.sum_partials(stats, B)
@@ -214,32 +228,32 @@ class _ConvAEFn(torch.autograd.Function):
         enc, dec, cls = model.encoder, model.decoder, model.sex_classifier
         # ---------------- encoder ----------------
         y0 = ops.conv1toC(x0, P["encoder.0.weight"], P["encoder.0.bias"], dt)
-        y1, st = cg(y0, pw("encoder.2.weight", "conv_fwd"), P["encoder.2.bias"], 32, 64, 2, 1,
+        y1, st = cg(y0, pw("encoder.2.weight", "conv_fwd"), "encoder.2.weight", P["encoder.2.bias"], 32, 64, 2, 1,
                                ops.taps_conv(K5, 1, 2), L2, swish=True, want_stats=True)
         n1 = inorm(st, L2, "encoder.3", 64)
-        y2, st = cg(y1, pw("encoder.5.weight", "conv_fwd"), P["encoder.5.bias"], 64, 64, 1, 1,
+        y2, st = cg(y1, pw("encoder.5.weight", "conv_fwd"), "encoder.5.weight", P["encoder.5.bias"], 64, 64, 1, 1,
                                ops.taps_conv(K5, 1, 2), L2, s1=n1[2], t1=n1[3], swish=True, want_stats=True)
         n2 = inorm(st, L2, "encoder.6", 64)
-        y3, st = cg(y2, pw("encoder.8.weight", "conv_fwd"), P["encoder.8.bias"], 64, 128, 2, 1,
+        y3, st = cg(y2, pw("encoder.8.weight", "conv_fwd"), "encoder.8.weight", P["encoder.8.bias"], 64, 128, 2, 1,
                                ops.taps_conv(K5, 1, 2), L4, s1=n2[2], t1=n2[3], swish=True, want_stats=True)
         n3 = inorm(st, L4, "encoder.9", 128)
-        y4, st = cg(y3, pw("encoder.11.weight", "conv_fwd"), P["encoder.11.bias"], 128, 128, 1, 1,
+        y4, st = cg(y3, pw("encoder.11.weight", "conv_fwd"), "encoder.11.weight", P["encoder.11.bias"], 128, 128, 1, 1,
                                ops.taps_conv(K5, 1, 2), L4, s1=n3[2], t1=n3[3], swish=True, want_stats=True)
         n4 = inorm(st, L4, "encoder.12", 128)
         # ---------------- sex classifier (GradReverse = identity forward) ----------------
         sums = ops.sum_partials(ops.act_stats(y4, n4[2], n4[3], True), 1) if train else None
         bn_n = bnorm(sums, B * L4, cls.norm, "sex_classifier.norm", 128)
         La, Lb, Lc = L4 - 4, L4 - 8, L4 - 14
-        r0, st = cg(y4, pw("sex_classifier.tdnn.0.weight", "conv_fwd"),
+        r0, st = cg(y4, pw("sex_classifier.tdnn.0.weight", "conv_fwd"), "sex_classifier.tdnn.0.weight",
                                P["sex_classifier.tdnn.0.bias"], 128, 128, 1, 1, ops.taps_conv(5, 1, 0), La,
                                s1=n4[2], t1=n4[3], swish=True, s2=bn_n[2], t2=bn_n[3], relu=True,
                                want_stats=True)
         bn0 = bnorm(ops.sum_partials(st, 1), B * La, cls.tdnn[2], "sex_classifier.tdnn.2", 128)
-        r1, st = cg(r0, pw("sex_classifier.tdnn.3.weight", "conv_fwd"),
+        r1, st = cg(r0, pw("sex_classifier.tdnn.3.weight", "conv_fwd"), "sex_classifier.tdnn.3.weight",
                                P["sex_classifier.tdnn.3.bias"], 128, 128, 1, 1, ops.taps_conv(3, 2, 0), Lb,
                                s2=bn0[2], t2=bn0[3], relu=True, want_stats=True)
         bn1 = bnorm(ops.sum_partials(st, 1), B * Lb, cls.tdnn[5], "sex_classifier.tdnn.5", 128)
-        r2, st = cg(r1, pw("sex_classifier.tdnn.6.weight", "conv_fwd"),
+        r2, st = cg(r1, pw("sex_classifier.tdnn.6.weight", "conv_fwd"), "sex_classifier.tdnn.6.weight",
                                P["sex_classifier.tdnn.6.bias"], 128, 128, 1, 1, ops.taps_conv(3, 3, 0), Lc,
                                s2=bn1[2], t2=bn1[3], relu=True, want_stats=True)
         bn2 = bnorm(ops.sum_partials(st, 1), B * Lc, cls.tdnn[8], "sex_classifier.tdnn.8", 128)
@@ -254,14 +268,14 @@ class _ConvAEFn(torch.autograd.Function):
                            2, 64, ps=f2[2], pt=f2[3])
         logp = ops.log_softmax(logits)
         # ---------------- decoder ----------------
-        y5 = cg(y4, pw("decoder.0.weight", "conv_fwd"), P["decoder.0.bias"], 128, 128, 1, 1,
+        y5 = cg(y4, pw("decoder.0.weight", "conv_fwd"), "decoder.0.weight", P["decoder.0.bias"], 128, 128, 1, 1,
                            ops.taps_conv(K5, 1, 2), L4, s1=n4[2], t1=n4[3], swish=True)
-        y6, st = cg(y5, pw("decoder.1.weight", "convT_fwd"), P["decoder.1.bias"], 128, 64, 1, 2,
+        y6, st = cg(y5, pw("decoder.1.weight", "convT_fwd"), "decoder.1.weight", P["decoder.1.bias"], 128, 64, 1, 2,
                                ops.UP2, L2, want_stats=True)
         n6 = inorm(st, L2, "decoder.2", 64)
-        y7 = cg(y6, pw("decoder.4.weight", "conv_fwd"), P["decoder.4.bias"], 64, 64, 1, 1,
+        y7 = cg(y6, pw("decoder.4.weight", "conv_fwd"), "decoder.4.weight", P["decoder.4.bias"], 64, 64, 1, 1,
                            ops.taps_conv(K5, 1, 2), L2, s1=n6[2], t1=n6[3], swish=True)
-        y8, st = cg(y7, pw("decoder.5.weight", "convT_fwd"), P["decoder.5.bias"], 64, 32, 1, 2,
+        y8, st = cg(y7, pw("decoder.5.weight", "convT_fwd"), "decoder.5.weight", P["decoder.5.bias"], 64, 32, 1, 2,
                                ops.UP2, Ltot, want_stats=True)
         n8 = inorm(st, Ltot, "decoder.6", 32)
         recon = ops.convCto1(y8, P["decoder.8.weight"], P["decoder.8.bias"], n8[2], n8[3], True)
@@ -269,7 +283,7 @@ class _ConvAEFn(torch.autograd.Function):
         S.update(x0=x0, y=[y0, y1, y2, y3, y4, y5, y6, y7, y8], r=[r0, r1, r2],
                  n=[None, n1, n2, n3, n4, None, n6, None, n8], bn=[bn_n, bn0, bn1, bn2], f=[f1, f2],
                  pooled=pooled, pmean=pmean, psd=psd, H1=H1, H2=H2, logp=logp,
-                 dims=(B, T, Ltot, L2, L4, La, Lb, Lc), train=train, W=W)
+                 dims=(B, T, Ltot, L2, L4, La, Lb, Lc), train=train, W=W, A=A)
         ctx.S, ctx.model, ctx.names, ctx.params = S, model, names, params
         ctx.need_input_grad = feats.requires_grad
         return recon.view(B, T, Fd), logp
@@ -297,7 +311,7 @@ class _ConvAEFn(torch.autograd.Function):
 
         def setg(key, val):
             G[key] = newg(key).copy_(val.reshape(P[key].shape))
-        W = S["W"]
+        W, A = S["W"], S["A"]
         pw = lambda k, kind: W[(k, kind)]
         cg = _conv
         wg = functools.partial(ops.wgrad, code=ops.WGRAD_CODE[model.precision])
@@ -356,12 +370,17 @@ class _ConvAEFn(torch.autograd.Function):
 
         def conv_wgrad(key, x, dy, cin, cout, sa, Mrows, K, dil, pad, **pro):
             if need[key]:
+                if key in A:
+                    x, pro = A[key], dict(x_pre=True)
                 G[key] = wg(x, dy, cin, cout, sa, 1, [(k * dil - pad, 0) for k in range(K)], Mrows,
                             newg(key), (K, cin * K, 1), **pro)
 
         def convT_wgrad(key, x, dy, cin, cout, Mrows):
             if need[key]:
-                G[key] = wg(x, dy, cin, cout, 1, 2, CONVT_WG_TAPS, Mrows, newg(key), (cout * K5, K5, 1))
+                pro = {}
+                if key in A:
+                    x, pro = A[key], dict(x_pre=True)
+                G[key] = wg(x, dy, cin, cout, 1, 2, CONVT_WG_TAPS, Mrows, newg(key), (cout * K5, K5, 1), **pro)
 
         if d_recon is None:
             d_recon = torch.zeros(B, T, 80, device=dev)

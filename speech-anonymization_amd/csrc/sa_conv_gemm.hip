@@ -148,6 +148,24 @@ __global__ __launch_bounds__(256) void sa_conv_gemm_kernel(SaConvArgs a, int red
   SA_STAMP(1);
   __syncthreads();
   SA_STAMP(2);
+  // activation cache for sa_wgrad (x_pre): the bf16 (hi) plane of the rows this tile owns -- its
+  // base rows, the last tile also the trailing halo -- goes out in 16-byte pieces; the stores
+  // drain while the MFMA loop runs
+  if constexpr (sizeof(LT) == 2) {
+    if (a.a_out) {
+      constexpr int CH16 = CIN / 8;
+      const int own_lo = m0 * SA;
+      int own_hi = tile == a.ntiles - 1 ? a.Lin : (m0 + C::BMB) * SA;
+      if (own_hi > a.Lin) own_hi = a.Lin;
+      const int rlo = own_lo - (m0 * SA + a.rowmin);
+      bf16_t* ao = reinterpret_cast<bf16_t*>(a.a_out) + ((size_t)b * a.Lin + own_lo) * CIN;
+      for (int e = tid; e < (own_hi - own_lo) * CH16; e += 256) {
+        const int r = e / CH16, c = e % CH16;
+        *reinterpret_cast<uint4*>(ao + (size_t)r * CIN + c * 8) =
+            *reinterpret_cast<const uint4*>(As + (size_t)(rlo + r) * C::APITCH + c * 8);
+      }
+    }
+  }
 
   // ---------------- main loop: MFMA over taps x channels -------------------------
   const int wn = wave % C::WN, wm = wave / C::WN;
@@ -360,6 +378,10 @@ static int launch_cfg(const SaConvArgs& a, hipStream_t st) {
   args.rowmin = omin;
   args.nrows = (C::BMB - 1) * SA + (omax - omin) + 1;
   args.wlo_off = (wmax + 1) * C::KSTEPS * C::NT * 64;      // Frag units: hi image size
+  // a_out: every input row must be staged by the tile that owns it
+  if (a.a_out && (sizeof(typename C::LT) != 2 || omin > 0 || (C::BMB - 1) * SA + omax < C::BMB * SA - 1 ||
+                  (args.ntiles - 1) * C::BMB * SA + omin + args.nrows < a.Lin))
+    return -22;
   const size_t lds = C::lds_bytes(args.nrows);
   if (lds > 160 * 1024) return -12;
   auto kern = sa_conv_gemm_kernel<T, CIN, COUT, SA, U, TM>;

@@ -15,6 +15,7 @@
 // sa_wgrad_reduce sums the slabs in a fixed order (deterministic) straight into the
 // PyTorch weight layout.
 #include "sa_common.h"
+#include <type_traits>
 
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 
@@ -155,10 +156,15 @@ __device__ static inline bf16x8 sa_tr_frag(const bf16_t* p, int rs) {
 // are transformed and written to the other buffer and the loads of K-tile i+2 are issued;
 // one barrier per K-tile.  Half of the waves stage first and multiply second, the other half
 // the other way round, so that the VALU and MFMA phases of the two waves on a SIMD overlap.
-template <typename T, int CIN, int COUT, int SA, int U>
+// XPRE: the A rows come pre-transformed in bf16 (SaConvArgs.a_out of the forward launch): 8 elements
+// per 16-byte chunk, no prologue arithmetic, and the registers that frees hold a second in-flight
+// K-tile (loads are issued two tiles ahead).
+template <typename T, int CIN, int COUT, int SA, int U, bool XPRE = false>
 struct WgCfg {
   typedef Pol<T> P;
   typedef typename P::lds_t LT;
+  static constexpr int VECA = XPRE ? 8 : P::VEC;
+  static constexpr int NSETS = XPRE ? 2 : 1;
   static constexpr int MT = CIN / 32, NT = COUT / 32, NP = MT * NT;
   static constexpr int NW = NP >= 8 ? 8 : 4;                       // waves per workgroup
   static constexpr int NTHR = NW * 64;
@@ -169,25 +175,26 @@ struct WgCfg {
   static constexpr int HALO = 8;                                   // max tap offset spread
   static constexpr int RA = KT * SA + HALO, RB = KT * U;           // staged rows
   static constexpr int PA = WgPitch<LT, CIN>::value, PB = WgPitch<LT, COUT>::value;
-  static constexpr int CHA = CIN / P::VEC, CHB = COUT / P::VEC;    // 16-byte chunks per row
+  static constexpr int CHA = CIN / VECA, CHB = COUT / P::VEC;      // 16-byte chunks per row
   static constexpr int NITA = (RA * CHA + NTHR - 1) / NTHR, NITB = (RB * CHB + NTHR - 1) / NTHR;
   static constexpr int AEL = P::NPL * RA * PA, BEL = P::NPL * RB * PB;     // lds_t elements
   static constexpr int BUFEL = (AEL + BEL + 7) & ~7;
   static constexpr size_t LDS = 2 * (size_t)BUFEL * sizeof(LT) + 4 * CIN * sizeof(float);
   static_assert(NW % NPG == 0 && NT % PPW == 0, "pair dealing");
   static_assert(NTHR % CHA == 0 && NTHR % CHB == 0, "chunk column must be fixed per thread");
+  static_assert(!XPRE || (sizeof(LT) == 2 && P::NPL == 1), "pre-transformed A is a bf16 single-plane operand");
 };
 
-template <typename T, int CIN, int COUT, int SA, int U>
-__global__ __launch_bounds__((WgCfg<T, CIN, COUT, SA, U>::NTHR)) void sa_wgrad_kernel(SaWgradArgs a) {
-  typedef WgCfg<T, CIN, COUT, SA, U> C;
+template <typename T, int CIN, int COUT, int SA, int U, bool XPRE>
+__global__ __launch_bounds__((WgCfg<T, CIN, COUT, SA, U, XPRE>::NTHR)) void sa_wgrad_kernel(SaWgradArgs a) {
+  typedef WgCfg<T, CIN, COUT, SA, U, XPRE> C;
   typedef Pol<T> P;
   typedef typename P::store_t S;
   typedef typename P::lds_t LT;
   typedef typename P::Frag Frag;
   typedef Tr<S> tr;
   constexpr int VEC = P::VEC, KS = P::KS, NPL = P::NPL, KT = C::KT, PPW = C::PPW;
-  constexpr int PA = C::PA, PB = C::PB, NTHR = C::NTHR;
+  constexpr int PA = C::PA, PB = C::PB, NTHR = C::NTHR, VECA = C::VECA, NSETS = C::NSETS;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   LT* tiles = reinterpret_cast<LT*>(smem);
   float* coef = reinterpret_cast<float*>(smem + 2 * (size_t)C::BUFEL * sizeof(LT));   // s1 t1 s2 t2
@@ -212,34 +219,36 @@ __global__ __launch_bounds__((WgCfg<T, CIN, COUT, SA, U>::NTHR)) void sa_wgrad_k
 
   // prologue coefficients of this utterance: LDS (read back per staged chunk, so that they do
   // not hold registers across the MFMA phase)
-  const bool has1 = a.s1 != nullptr, has2 = a.s2 != nullptr, sw = a.swish != 0;
+  const bool has1 = !XPRE && a.s1 != nullptr, has2 = !XPRE && a.s2 != nullptr, sw = !XPRE && a.swish != 0;
   for (int ch = tid; ch < CIN; ch += NTHR) {
     coef[ch] = has1 ? a.s1[(size_t)b * CIN + ch] : 1.0f;
     coef[CIN + ch] = has1 ? a.t1[(size_t)b * CIN + ch] : 0.0f;
     coef[2 * CIN + ch] = has2 ? a.s2[ch] : 1.0f;
     coef[3 * CIN + ch] = has2 ? a.t2[ch] : 0.0f;
   }
-  const S* xb = reinterpret_cast<const S*>(a.x) + (size_t)b * a.Lin * CIN;
+  typedef typename std::conditional<XPRE, bf16_t, S>::type SX;        // storage type of the A rows
+  const SX* xb = reinterpret_cast<const SX*>(a.x) + (size_t)b * a.Lin * CIN;
   const S* yb = reinterpret_cast<const S*>(a.dy) + (size_t)b * a.Ldy * COUT;
   const int dyend = mend * U < a.Ldy ? mend * U : a.Ldy;
   const int ca = tid % C::CHA, ra0 = tid / C::CHA, cb = tid % C::CHB, rb0 = tid / C::CHB;
   constexpr int RSA = NTHR / C::CHA, RSB = NTHR / C::CHB;           // row step per iteration slot
 
-  uint4 rawA[C::NITA], rawB[C::NITB];
-  auto issue = [&](int m0) {
+  struct RegSet { uint4 a[C::NITA]; uint4 b[C::NITB]; };
+  RegSet set0, set1;
+  auto issue = [&](RegSet& rs, int m0) {
 #pragma unroll
     for (int i = 0; i < C::NITA; ++i) {
       const int r = ra0 + i * RSA, g = m0 * SA + offmin + r;
-      rawA[i] = make_uint4(0, 0, 0, 0);
+      rs.a[i] = make_uint4(0, 0, 0, 0);
       if (m0 < mend && r < C::RA && g >= 0 && g < a.Lin)
-        rawA[i] = *reinterpret_cast<const uint4*>(xb + (size_t)g * CIN + ca * VEC);
+        rs.a[i] = *reinterpret_cast<const uint4*>(xb + (size_t)g * CIN + ca * VECA);
     }
 #pragma unroll
     for (int i = 0; i < C::NITB; ++i) {
       const int r = rb0 + i * RSB, g = m0 * U + r;
-      rawB[i] = make_uint4(0, 0, 0, 0);
+      rs.b[i] = make_uint4(0, 0, 0, 0);
       if (m0 < mend && r < C::RB && g < dyend)
-        rawB[i] = *reinterpret_cast<const uint4*>(yb + (size_t)g * COUT + cb * VEC);
+        rs.b[i] = *reinterpret_cast<const uint4*>(yb + (size_t)g * COUT + cb * VEC);
     }
   };
   auto put = [&](LT* base, int planes_stride, int pitch, int r, int c, const float* f) {
@@ -255,34 +264,42 @@ __global__ __launch_bounds__((WgCfg<T, CIN, COUT, SA, U>::NTHR)) void sa_wgrad_k
       *reinterpret_cast<uint4*>(dst) = tr::pack(f);
     }
   };
-  auto stage = [&](LT* At, int m0) {
+  auto stage = [&](LT* At, const RegSet& rs, int m0) {
     LT* Bt = At + C::AEL;
-    float s1r[VEC], t1r[VEC], s2r[VEC], t2r[VEC];
-    if (has1 || has2) {
+    if constexpr (XPRE) {
 #pragma unroll
-      for (int j = 0; j < VEC; ++j) {
-        s1r[j] = coef[ca * VEC + j]; t1r[j] = coef[CIN + ca * VEC + j];
-        s2r[j] = coef[2 * CIN + ca * VEC + j]; t2r[j] = coef[3 * CIN + ca * VEC + j];
+      for (int i = 0; i < C::NITA; ++i) {
+        const int r = ra0 + i * RSA;
+        if (r < C::RA) *reinterpret_cast<uint4*>(At + (size_t)r * PA + ca * VECA) = rs.a[i];
       }
-    }
+    } else {
+      float s1r[VEC], t1r[VEC], s2r[VEC], t2r[VEC];
+      if (has1 || has2) {
 #pragma unroll
-    for (int i = 0; i < C::NITA; ++i) {
-      const int r = ra0 + i * RSA;
-      if (r < C::RA) {
-        const int g = m0 * SA + offmin + r;
-        float f[VEC];
-        tr::unpack(rawA[i], f);
-        if ((has1 || has2 || sw) && g >= 0 && g < a.Lin) {
-#pragma unroll
-          for (int j = 0; j < VEC; ++j) {
-            float v = f[j];
-            if (has1) v = fmaf(v, s1r[j], t1r[j]);
-            if (sw) v = sa_swish(v);
-            if (has2) v = fmaf(v, s2r[j], t2r[j]);
-            f[j] = v;
-          }
+        for (int j = 0; j < VEC; ++j) {
+          s1r[j] = coef[ca * VEC + j]; t1r[j] = coef[CIN + ca * VEC + j];
+          s2r[j] = coef[2 * CIN + ca * VEC + j]; t2r[j] = coef[3 * CIN + ca * VEC + j];
         }
-        put(At, C::RA * PA, PA, r, ca, f);
+      }
+#pragma unroll
+      for (int i = 0; i < C::NITA; ++i) {
+        const int r = ra0 + i * RSA;
+        if (r < C::RA) {
+          const int g = m0 * SA + offmin + r;
+          float f[VEC];
+          tr::unpack(rs.a[i], f);
+          if ((has1 || has2 || sw) && g >= 0 && g < a.Lin) {
+#pragma unroll
+            for (int j = 0; j < VEC; ++j) {
+              float v = f[j];
+              if (has1) v = fmaf(v, s1r[j], t1r[j]);
+              if (sw) v = sa_swish(v);
+              if (has2) v = fmaf(v, s2r[j], t2r[j]);
+              f[j] = v;
+            }
+          }
+          put(At, C::RA * PA, PA, r, ca, f);
+        }
       }
     }
 #pragma unroll
@@ -290,7 +307,7 @@ __global__ __launch_bounds__((WgCfg<T, CIN, COUT, SA, U>::NTHR)) void sa_wgrad_k
       const int r = rb0 + i * RSB;
       if (r < C::RB) {
         float f[VEC];
-        tr::unpack(rawB[i], f);
+        tr::unpack(rs.b[i], f);
         put(Bt, C::RB * PB, PB, r, cb, f);
       }
     }
@@ -352,25 +369,31 @@ __global__ __launch_bounds__((WgCfg<T, CIN, COUT, SA, U>::NTHR)) void sa_wgrad_k
     }
   };
 
-  issue(mbeg);
+  issue(set0, mbeg);
+  if constexpr (NSETS == 2) issue(set1, mbeg + KT);
   __syncthreads();                                   // coefficients visible
-  stage(tiles, mbeg);
-  issue(mbeg + KT);
+  stage(tiles, set0, mbeg);
+  issue(set0, mbeg + NSETS * KT);
   __syncthreads();
   const bool stage_first = wave < C::NW / 2;
-  int cur = 0;
-  for (int m0 = mbeg; m0 < mend; m0 += KT, cur ^= 1) {
+  // tile i is multiplied from buffer i&1 while tile i+1 (register set `rs`) is staged into the
+  // other buffer and the set is re-issued NSETS tiles ahead
+  auto step = [&](RegSet& rs, int m0, int cur) {
     LT* now = tiles + (size_t)cur * C::BUFEL;
     LT* nxt = tiles + (size_t)(cur ^ 1) * C::BUFEL;
     const bool more = m0 + KT < mend;
     if (stage_first) {
-      if (more) { stage(nxt, m0 + KT); issue(m0 + 2 * KT); }
+      if (more) { stage(nxt, rs, m0 + KT); issue(rs, m0 + KT + NSETS * KT); }
       mfma_tile(now);
     } else {
       mfma_tile(now);
-      if (more) { stage(nxt, m0 + KT); issue(m0 + 2 * KT); }
+      if (more) { stage(nxt, rs, m0 + KT); issue(rs, m0 + KT + NSETS * KT); }
     }
     __syncthreads();
+  };
+  for (int m0 = mbeg; m0 < mend; m0 += 2 * KT) {
+    step(NSETS == 2 ? set1 : set0, m0, 0);
+    if (m0 + KT < mend) step(set0, m0 + KT, 1);
   }
 
   // ---- fp32 partial slab [kw][tap][CIN][COUT] of this (utterance, chunk) ----
@@ -394,9 +417,9 @@ extern "C" int sa_wgrad_kw(int cin, int cout) {
   return nw / (np / ppw);
 }
 
-template <typename T, int CIN, int COUT, int SA, int U>
+template <typename T, int CIN, int COUT, int SA, int U, bool XPRE = false>
 static int launch_wgrad(const SaWgradArgs& a, hipStream_t st) {
-  typedef WgCfg<T, CIN, COUT, SA, U> C;
+  typedef WgCfg<T, CIN, COUT, SA, U, XPRE> C;
   int omin = a.off[0], omax = a.off[0];
   for (int t = 1; t < a.ntaps; ++t) {
     omin = a.off[t] < omin ? a.off[t] : omin;
@@ -405,7 +428,7 @@ static int launch_wgrad(const SaWgradArgs& a, hipStream_t st) {
   if (omax - omin > C::HALO) return -22;
   for (int t = 0; t < a.ntaps; ++t) if (a.ph[t] < 0 || a.ph[t] >= U) return -22;
   if (C::LDS > 160 * 1024) return -12;
-  auto kern = sa_wgrad_kernel<T, CIN, COUT, SA, U>;
+  auto kern = sa_wgrad_kernel<T, CIN, COUT, SA, U, XPRE>;
   static bool attr_set = false;
   if (!attr_set) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
@@ -423,14 +446,16 @@ static int launch_wgrad(const SaWgradArgs& a, hipStream_t st) {
   if (cin == CI && cout == CO && sa == S && u == UU)                            \
     return dtype == SA_BF16 ? launch_wgrad<bf16_t, CI, CO, S, UU>(*a, st)       \
            : dtype == SA_BF16X3 ? launch_wgrad<bf16x3_t, CI, CO, S, UU>(*a, st) \
-           : dtype == SA_BF16X1F ? launch_wgrad<bf16x1f_t, CI, CO, S, UU>(*a, st) \
+           : dtype == SA_BF16X1F ? (a->x_pre ? launch_wgrad<bf16x1f_t, CI, CO, S, UU, true>(*a, st)  \
+                                             : launch_wgrad<bf16x1f_t, CI, CO, S, UU>(*a, st)) \
                                 : launch_wgrad<float, CI, CO, S, UU>(*a, st);
 
 extern "C" int sa_wgrad(int dtype, int cin, int cout, int sa, int u, const SaWgradArgs* a,
                         void* stream) {
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   if (!a || !a->x || !a->dy || !a->slabs || a->ntaps < 1 || a->ntaps > SA_MAX_TAPS ||
-      a->chunk <= 0 || a->chunk % 64 || a->nchunk * a->chunk < a->Mrows)
+      a->chunk <= 0 || a->chunk % 64 || a->nchunk * a->chunk < a->Mrows ||
+      (a->x_pre && dtype != SA_BF16X1F))
     return -22;
   SA_WG_CASE(32, 64, 2, 1)
   SA_WG_CASE(64, 64, 1, 1)

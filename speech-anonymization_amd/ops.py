@@ -136,10 +136,11 @@ class PackedWeights:
 
 
 def conv_gemm(x, wp, bias, cin, cout, sa, u, phases, Lout, s1=None, t1=None, s2=None, t2=None,
-              swish=False, relu=False, want_stats=False, out=None, code=None, ep=None):
+              swish=False, relu=False, want_stats=False, out=None, code=None, ep=None, a_out=None):
     """x [B, Lin, cin] -> y [B, Lout, cout] (+ per-tile partial stats [B, ntiles, cout, 2]).
     ep: fused backward epilogue dict(mode=1|2, x=, g2=, s1=, t1=, mean=, rstd=, xp_is_act=,
-    per_c=) -- see SaConvArgs.ep_* in include/sa_hip.h."""
+    per_c=) -- see SaConvArgs.ep_* in include/sa_hip.h.  a_out: optional bf16 [B, Lin, cin] tensor
+    that receives the transformed input rows (the A operand of wgrad(..., x_pre=True))."""
     lib = L.load()
     B, Lin, _ = x.shape
     assert x.shape[2] == cin
@@ -152,6 +153,9 @@ def conv_gemm(x, wp, bias, cin, cout, sa, u, phases, Lout, s1=None, t1=None, s2=
     a.swish, a.relu, a.stats = int(swish), int(relu), _f(stats)
     a.B, a.Lin, a.Lout = B, Lin, Lout
     a.taps = L.make_taps(phases)
+    if a_out is not None:
+        assert a_out.dtype == torch.bfloat16 and a_out.shape == x.shape
+        a.a_out = _f(a_out)
     if ep:
         a.ep_mode, a.ep_xp_is_act = int(ep["mode"]), int(bool(ep.get("xp_is_act")))
         a.ep_bstride = 0 if ep.get("per_c") else cout
@@ -174,12 +178,15 @@ WGRAD_TARGET_WGS = {True: 256, False: 512}
 
 
 def wgrad(x, dy, cin, cout, sa, u, taps, Mrows, dst, dst_strides, s1=None, t1=None, s2=None,
-          t2=None, swish=False, accumulate=False, target_wgs=None, code=None):
+          t2=None, swish=False, accumulate=False, target_wgs=None, code=None, x_pre=False):
     """taps: list of (row_offset, phase) per weight tap.  dst: fp32 parameter-gradient tensor in
-    PyTorch layout; dst_strides = (s_ci, s_co, s_tap)."""
+    PyTorch layout; dst_strides = (s_ci, s_co, s_tap).  x_pre: x is the bf16 a_out tensor of the
+    forward conv_gemm (already transformed; s1..swish are ignored)."""
     lib = L.load()
     B, Lin, _ = x.shape
     Ldy = dy.shape[1]
+    if x_pre:
+        assert x.dtype == torch.bfloat16 and code == L.BF16X1F
     nt = len(taps)
     kw = lib.sa_wgrad_kw(cin, cout)
     if target_wgs is None:
@@ -196,7 +203,8 @@ def wgrad(x, dy, cin, cout, sa, u, taps, Mrows, dst, dst_strides, s1=None, t1=No
     a.B, a.Lin, a.Ldy, a.Mrows, a.chunk, a.nchunk, a.ntaps = B, Lin, Ldy, Mrows, chunk, nchunk, nt
     for i, (off, ph) in enumerate(taps):
         a.off[i], a.ph[i] = off, ph
-    L.check(lib.sa_wgrad(L.dt_code(x.dtype) if code is None else code, cin, cout, sa, u,
+    a.x_pre = int(x_pre)
+    L.check(lib.sa_wgrad(L.dt_code(dy.dtype) if code is None else code, cin, cout, sa, u,
                          C.byref(a), L.stream()),
             f"sa_wgrad({cin},{cout},{sa},{u})")
     sk, sn, st = dst_strides

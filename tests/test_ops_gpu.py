@@ -463,3 +463,43 @@ def test_pack_weights_multi_matches_single():
         one = ops.pack_weights(w, kind, torch.bfloat16 if code == L.BF16 else torch.float32, code)
         assert c == code and img.numel() == one.numel()
         assert torch.equal(img.view(torch.uint8), one.view(torch.uint8))
+
+
+@pytest.mark.parametrize("cfg", [(128, 128, 1, 1, 5, 1, 2), (64, 128, 2, 1, 5, 1, 2), (128, 128, 1, 1, 3, 2, 0),
+                                 (128, 64, 1, 2, 5, 1, 2), (32, 64, 2, 1, 5, 1, 2)])
+def test_wgrad_from_cached_operand_is_bit_identical(cfg):
+    """sa_conv_gemm's a_out (bf16 transformed input) fed to sa_wgrad(x_pre) == sa_wgrad recomputing
+    the transform from the fp32 rows: same products, same order -> same bits."""
+    from speech_anonymization_amd import _lib as L, ops
+    cin, cout, sa, u, K, dil, pad = cfg
+    d = dev()
+    g = torch.Generator(device="cpu").manual_seed(11)
+    B = 3
+    if u == 2:
+        Lin, Lout = 203, 406
+        w = torch.randn(cin, cout, 5, generator=g).to(d) * 0.1
+        wp, phases = ops.pack_weights(w, "convT_fwd", torch.float32, L.BF16X3), ops.UP2
+        taps, Mrows, dst, strides = [(1, 0), (1, 1), (0, 0), (0, 1), (-1, 0)], Lin, torch.empty(cin, cout, 5, device=d), (cout * 5, 5, 1)
+    else:
+        Lin = 406 if sa == 1 else 407
+        Lout = (Lin + 2 * pad - dil * (K - 1) - 1) // sa + 1
+        w = torch.randn(cout, cin, K, generator=g).to(d) * 0.1
+        wp, phases = ops.pack_weights(w, "conv_fwd", torch.float32, L.BF16X3), ops.taps_conv(K, dil, pad)
+        taps, Mrows, dst, strides = [(k * dil - pad, 0) for k in range(K)], Lout, torch.empty(cout, cin, K, device=d), (K, cin * K, 1)
+    x = torch.randn(B, Lin, cin, generator=g).to(d)
+    s1 = (torch.rand(B, cin, generator=g) + 0.5).to(d)
+    t1 = (torch.randn(B, cin, generator=g) * 0.1).to(d)
+    s2 = (torch.rand(cin, generator=g) + 0.5).to(d)
+    t2 = (torch.randn(cin, generator=g) * 0.1).to(d)
+    a_out = torch.full((B, Lin, cin), float("nan"), dtype=torch.bfloat16, device=d)
+    ops.conv_gemm(x, wp, None, cin, cout, sa, u, phases, Lout, s1=s1, t1=t1, swish=True, s2=s2, t2=t2,
+                  code=L.BF16X3, a_out=a_out)
+    assert not torch.isnan(a_out.float()).any()          # every input row was written by its owner tile
+    ref = torch.nn.functional.silu(x * s1[:, None, :] + t1[:, None, :]) * s2 + t2
+    assert rel_mse(a_out.float(), ref) < 1e-5
+    dy = torch.randn(B, Lout, cout, generator=g).to(d)
+    d1, d2 = torch.empty_like(dst), torch.empty_like(dst)
+    ops.wgrad(x, dy, cin, cout, sa, u, taps, Mrows, d1, strides, s1=s1, t1=t1, swish=True, s2=s2, t2=t2,
+              code=L.BF16X1F)
+    ops.wgrad(a_out, dy, cin, cout, sa, u, taps, Mrows, d2, strides, code=L.BF16X1F, x_pre=True)
+    assert torch.equal(d1, d2)
