@@ -65,7 +65,10 @@ struct ConvCfg {
     size_t m = a > o ? a : o;
     return (m + 15) & ~(size_t)15;
   }
-  static size_t lds_bytes(int nrows) { return tile_bytes(nrows) + (size_t)RPPO * COUT * 2 * sizeof(float); }
+  static size_t lds_bytes(int nrows) {                 // the statistics scratch overlays the tile
+    size_t t = tile_bytes(nrows), r = (size_t)RPPO * COUT * 2 * sizeof(float);
+    return t > r ? t : r;
+  }
 };
 
 template <typename T, int CIN, int COUT, int SA, int U, int TM>
@@ -112,6 +115,10 @@ __global__ __launch_bounds__(256) void sa_conv_gemm_kernel(SaConvArgs a, int red
       raw[i] = make_uint4(0, 0, 0, 0);
       if (r < a.nrows && g >= 0 && g < a.Lin) raw[i] = *reinterpret_cast<const uint4*>(xb + (size_t)g * CIN);
     }
+#ifdef SA_CONV_STAMPS
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    SA_STAMP(1);                                      // all row loads have landed
+#endif
 #pragma unroll
     for (int i = 0; i < NIT; ++i) {
       const int r = r0 + i * C::RPPI, g = gbase + r;
@@ -145,7 +152,6 @@ __global__ __launch_bounds__(256) void sa_conv_gemm_kernel(SaConvArgs a, int red
       }
     }
   }
-  SA_STAMP(1);
   __syncthreads();
   SA_STAMP(2);
   // activation cache for sa_wgrad (x_pre): the bf16 (hi) plane of the rows this tile owns -- its
@@ -180,7 +186,7 @@ __global__ __launch_bounds__(256) void sa_conv_gemm_kernel(SaConvArgs a, int red
   // Weight fragments (B operand) come straight from global memory (L2-resident image); they are
   // software-pipelined one group of KU k-steps ahead in registers so their latency hides
   // behind the previous group's MFMAs (two statically indexed register buffers, ping-pong).
-  constexpr int KUP = P::NPL == 2 ? 4 : 8;
+  constexpr int KUP = P::NPL == 2 ? 2 : 8;
   constexpr int KU = C::KSTEPS < KUP ? C::KSTEPS : KUP;
   constexpr int GPT = C::KSTEPS / KU;                // groups per tap
   static_assert(C::KSTEPS % KU == 0, "k-steps per tap must be a multiple of the prefetch group");
@@ -243,25 +249,8 @@ __global__ __launch_bounds__(256) void sa_conv_gemm_kernel(SaConvArgs a, int red
     }
   }
   SA_STAMP(3);
-  // fused backward epilogue (ep_mode != 0): the stored forward tensor (and an optional second
-  // gradient) of this thread's output chunks are requested now, so the loads fly during the
-  // accumulator transpose below
   constexpr int NOT = TM / C::RPPO;
   const int ec = tid % C::CHO, er0 = tid / C::CHO;
-  uint4 epx[NOT], epg[NOT];
-  if (a.ep_mode) {
-    const S* xe = reinterpret_cast<const S*>(a.ep_x) + (size_t)b * a.Lout * COUT + ec * OVEC;
-    const S* ge = a.ep_g2 ? reinterpret_cast<const S*>(a.ep_g2) + (size_t)b * a.Lout * COUT + ec * OVEC : nullptr;
-#pragma unroll
-    for (int i = 0; i < NOT; ++i) {
-      const int o = m0 * U + er0 + i * C::RPPO;
-      epx[i] = make_uint4(0, 0, 0, 0); epg[i] = make_uint4(0, 0, 0, 0);
-      if (o < a.Lout) {
-        epx[i] = *reinterpret_cast<const uint4*>(xe + (size_t)o * COUT);
-        if (ge) epg[i] = *reinterpret_cast<const uint4*>(ge + (size_t)o * COUT);
-      }
-    }
-  }
   __syncthreads();                                   // every wave is done reading As
   SA_STAMP(4);
 
@@ -297,6 +286,8 @@ __global__ __launch_bounds__(256) void sa_conv_gemm_kernel(SaConvArgs a, int red
       ers[j] = (a.ep_mode && a.ep_rstd) ? a.ep_rstd[(size_t)b * a.ep_bstride + c * OVEC + j] : 1.0f;
     }
     S* yb = reinterpret_cast<S*>(a.y) + (size_t)b * a.Lout * COUT + c * OVEC;
+    const S* xe = a.ep_mode ? reinterpret_cast<const S*>(a.ep_x) + (size_t)b * a.Lout * COUT + c * OVEC : nullptr;
+    const S* ge = (a.ep_mode && a.ep_g2) ? reinterpret_cast<const S*>(a.ep_g2) + (size_t)b * a.Lout * COUT + c * OVEC : nullptr;
     const int o0 = m0 * U;
 #pragma unroll
     for (int i = 0; i < NOT; ++i) {
@@ -304,10 +295,15 @@ __global__ __launch_bounds__(256) void sa_conv_gemm_kernel(SaConvArgs a, int red
       if (o < a.Lout) {
         uint4 u = *reinterpret_cast<const uint4*>(Os + (size_t)r * C::OPITCH + c * OVEC);
         if (a.ep_mode) {
+          // The stored forward tensor (and the optional second gradient) are fetched here, one
+          // row group at a time: prefetching all of them before the accumulator transpose costs
+          // 64 registers and with them a resident workgroup per CU.
+          const uint4 epx = *reinterpret_cast<const uint4*>(xe + (size_t)o * COUT);
+          const uint4 epg = ge ? *reinterpret_cast<const uint4*>(ge + (size_t)o * COUT) : make_uint4(0, 0, 0, 0);
           // mode 1: g' = (g + g2) * swish'(z), xhat from x (InstanceNorm + x*sigmoid(x) block)
           // mode 2: g' = g + g2, xhat from x, or from swish(z) when ep_xp_is_act (BatchNorm blocks)
           float g[OVEC], x[OVEC], g2[OVEC], xn[OVEC];
-          tr::unpack(u, g); tr::unpack(epx[i], x); tr::unpack(epg[i], g2);
+          tr::unpack(u, g); tr::unpack(epx, x); tr::unpack(epg, g2);
 #pragma unroll
           for (int j = 0; j < OVEC; ++j) {
             const float z = fmaf(x[j], es1[j], et1[j]);
@@ -336,6 +332,7 @@ __global__ __launch_bounds__(256) void sa_conv_gemm_kernel(SaConvArgs a, int red
       }
     }
     if (a.stats) {
+      __syncthreads();                               // Os fully consumed: red overlays it
 #pragma unroll
       for (int j = 0; j < OVEC; ++j) {
         red[((size_t)r0 * COUT + c * OVEC + j) * 2 + 0] = ssum[j];
@@ -393,16 +390,19 @@ static int launch_cfg(const SaConvArgs& a, hipStream_t st) {
     attr_set = true;
   }
   dim3 grid(args.ntiles, a.B);
-  hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, args, (int)C::tile_bytes(args.nrows));
+  hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, args, 0);
   hipError_t e = hipGetLastError();
   return e == hipSuccess ? 0 : -(int)e;
 }
 
-// Output rows per workgroup.  64-row tiles keep 4-6 workgroups resident per CU so that one
-// workgroup's HBM staging / epilogue overlaps another's MFMA phase (the 128-row tile leaves
-// only 2-3 resident and showed ~60 % of the launch outside the MFMA loop); the 64->32 U=2 layer
+// Output rows per workgroup, chosen per shape from measurements at the training sizes (B=32,
+// 161k-sample utterances): 64-row tiles keep 4-5 workgroups resident per CU so that one
+// workgroup's HBM staging / epilogue overlaps another's MFMA phase; 128-row tiles halve the
+// weight-fragment traffic per output row and win where the 128-row kernel still fits three
+// workgroups per CU (64->64 k5: 301 -> 255 us, 128->64 U=2: 316 -> 301 us), lose where registers
+// and LDS leave two (128->128: 469 -> 520 us, 64->128 s2: 264 -> 368 us).  The 64->32 U=2 layer
 // needs 128 rows to give every wave a full 32-row m-tile.  sa_conv_gemm_set_tile_rows() is a
-// tuning knob (0 = default policy).
+// tuning knob (0 = this policy).
 static int g_tile_rows = 0;
 extern "C" int sa_conv_gemm_set_tile_rows(int rows) {
   if (rows != 0 && rows != 64 && rows != 128) return -22;
@@ -411,7 +411,9 @@ extern "C" int sa_conv_gemm_set_tile_rows(int rows) {
 }
 static int tile_rows(int cin, int cout, int u) {
   if (cin == 64 && cout == 32 && u == 2) return 128;
-  return g_tile_rows ? g_tile_rows : 64;
+  if (g_tile_rows) return g_tile_rows;
+  if ((cin == 64 && cout == 64) || (cin == 128 && cout == 64 && u == 2)) return 128;
+  return 64;
 }
 
 // number of (sum, sumsq) partial tiles per utterance the epilogue writes

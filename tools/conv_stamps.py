@@ -28,7 +28,7 @@ for prec in ("bf16x3", "bf16"):
     full = full[full[:, 0] > 0]
     a = full[:, :7]
     d = np.diff(a, axis=1)
-    names = ["prologue(load+xform+lds)", "barrier", "MFMA loop", "ep loads", "barrier", "acc->LDS + barrier", "store+stats"]
+    names = ["row loads land", "xform + LDS write + barrier", "MFMA loop", "barrier (As free)", "acc->LDS + barrier", "store + stats"]
     print(prec, "workgroups sampled:", len(a))
     for n, v in zip(names, np.median(d, axis=0)):
         print(f"   {n:26s} {v:9.0f} cycles")

@@ -6,6 +6,9 @@ import torch
 from speech_anonymization_amd import ops
 
 dev = torch.device("cuda:0")
+if os.environ.get("KB_TILE_ROWS"):                     # conv tile rows knob (64 | 128)
+    from speech_anonymization_amd import _lib as _L
+    assert _L.load().sa_conv_gemm_set_tile_rows(int(os.environ["KB_TILE_ROWS"])) == 0
 if os.environ.get("KB_WG_TARGET"):                     # "big,small" workgroup-count targets of ops.wgrad
     _b, _s = os.environ["KB_WG_TARGET"].split(",")
     ops.WGRAD_TARGET_WGS.update({True: int(_b), False: int(_s)})
