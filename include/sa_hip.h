@@ -113,8 +113,11 @@ int sa_wgrad_reduce(const float* slabs, float* dst, int nslab, int ntaps, int ci
 
 /* ---- single-channel ends (sa_small.hip): encoder.0 Conv1d(1,32,15,p7) / decoder.8
  * Conv1d(32,1,15,p7), models/ConvAutoEncoder.py:142,171 ------------------------------- */
+/* stats [B][ntiles][32][2].  ep_x (optional, y's layout): backward epilogue -- y = conv * swish'(z),
+ * z = ep_x*ep_s1[b][c]+ep_t1[b][c]; stats = (sum y, sum y*(ep_x-ep_mean[b][c])*ep_rstd[b][c]) */
 int sa_conv1toC(int dtype, const float* x, const float* w, const float* bias, void* y, int B, int L,
-                int flip, float* stats, void* stream);          /* stats [B][ntiles][32][2] */
+                int flip, float* stats, const void* ep_x, const float* ep_s1, const float* ep_t1,
+                const float* ep_mean, const float* ep_rstd, void* stream);
 int sa_conv1toC_ntiles(int L);
 int sa_convCto1(int dtype, const void* x, const float* w, const float* bias, float* y, int B, int L,
                 const float* s1, const float* t1, int swish, int flip, void* stream);
@@ -164,9 +167,11 @@ int sa_pool_fwd(int dtype, const void* r, const float* scale, const float* shift
 int sa_pool_ntiles(int L);
 int sa_pool_fin(const double* sums, int B, int n, const float* noise, float eps, float* pooled,
                 float* mean, float* stdraw, void* stream);
+/* stats (optional, [B][ceil(L/256)][128][2]): partial (sum g, sum g*(r-bn_mean[c])*bn_rstd[c]) of
+ * the written gradient, i.e. what sa_ew_stats would compute from g and r in a second pass */
 int sa_pool_bwd(int dtype, const void* r, const float* scale, const float* shift,
                 const float* dpooled, const float* mean, const float* stdraw, void* g, int B, int L,
-                void* stream);
+                const float* bn_mean, const float* bn_rstd, float* stats, void* stream);
 int sa_dense(const float* X, int lda, const float* ps, const float* pt, const float* W, int sbk,
              int sbn, const float* bias, float* Y, int ldy, int M, int N, int K, int relu,
              void* stream);

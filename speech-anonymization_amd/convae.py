@@ -337,12 +337,6 @@ class _ConvAEFn(torch.autograd.Function):
             bias_from(st2, bias_key, C)
             return g                                             # now d y
 
-        def in_block(g, y, nrm, C, Ln, prefix, bias_key):
-            """unfused form (the incoming gradient does not come from sa_conv_gemm)."""
-            mean, rstd, scale, shift = nrm
-            st = ops.ew("stats", g, y, C, out=g, s1=scale, t1=shift, mean=mean, rstd=rstd, actbwd=True)
-            return in_finish(g, st, y, nrm, C, Ln, prefix, bias_key)
-
         def bn_ep(r, bn, xp=None):
             d = dict(mode=2, x=r, mean=bn[0], rstd=bn[1], per_c=True)
             if xp:
@@ -408,8 +402,7 @@ class _ConvAEFn(torch.autograd.Function):
         setg(c + "0.bias", ops.colsums(dH1)[:, 0])
         dP = ops.dense(dH1, P[c + "0.weight"], None, 256, 128, transpose_w=True)
         t = "sex_classifier.tdnn."
-        g = ops.pool_bwd(r2, bn2[2], bn2[3], dP, S["pmean"], S["psd"])
-        st = ops.ew("stats", g, r2, 128, mean=bn2[0], rstd=bn2[1], per_c=True)
+        g, st = ops.pool_bwd(r2, bn2[2], bn2[3], dP, S["pmean"], S["psd"], bn=(bn2[0], bn2[1]))
         g = bn_finish(g, st, r2, bn2, Lc, t + "8", t + "6.bias")
         conv_wgrad(t + "6.weight", r1, g, 128, 128, 1, Lc, 3, 3, 0, s2=bn1[2], t2=bn1[3])
         g, st = cg(g, pw(t + "6.weight", "conv_dgrad"), None, 128, 128, 1, 1,
@@ -434,8 +427,9 @@ class _ConvAEFn(torch.autograd.Function):
         if need["decoder.8.weight"]:
             G["decoder.8.weight"] = ops.wgrad1C(g_rec, y8, newg("decoder.8.weight"), flip=True,
                                                 s1=n8[2], t1=n8[3], swish=True)
-        g = ops.conv1toC(g_rec, P["decoder.8.weight"], None, dt, flip=True)                # d a8
-        g = in_block(g, y8, n8, 32, Ltot, "decoder.6", "decoder.5.bias")                    # d y8
+        g, st = ops.conv1toC(g_rec, P["decoder.8.weight"], None, dt, flip=True, want_stats=True,
+                             ep=dict(x=y8, s1=n8[2], t1=n8[3], mean=n8[0], rstd=n8[1]))     # d z8
+        g = in_finish(g, st, y8, n8, 32, Ltot, "decoder.6", "decoder.5.bias")               # d y8
         convT_wgrad("decoder.5.weight", y7, g, 64, 32, L2)
         g, st = cg(g, pw("decoder.5.weight", "convT_dgrad"), None, 32, 64, 2, 1,
                    ops.taps_convT_dgrad(), L2, want_stats=True)                              # d y7

@@ -113,6 +113,9 @@ extern "C" int sa_pool_fin(const double* sums, int B, int n, const float* noise,
 
 // Pooling backward: g[b][l][c] = dmean_j/n + dstd_j * (xbn - mean_j) / ((n-1) * std_j),
 // j = (c*L + l) % 128, xbn = r*scale[c] + shift[c].   dpooled [B][256].
+// With stats != null the kernel also leaves the partial sums the BatchNorm backward of the
+// pooled tensor needs, (sum g, sum g*(r - bn_mean[c])*bn_rstd[c]) per channel, one slab per
+// workgroup [B][ceil(L/256)][128][2] (a separate sa_ew_stats pass would re-read g and r).
 template <typename T>
 __global__ __launch_bounds__(256) void sa_pool_bwd_kernel(const T* __restrict__ r,
                                                           const float* __restrict__ sc,
@@ -120,9 +123,13 @@ __global__ __launch_bounds__(256) void sa_pool_bwd_kernel(const T* __restrict__ 
                                                           const float* __restrict__ dpooled,
                                                           const float* __restrict__ mean,
                                                           const float* __restrict__ stdraw,
-                                                          T* __restrict__ g, int L) {
+                                                          T* __restrict__ g, int L,
+                                                          const float* __restrict__ bn_mean,
+                                                          const float* __restrict__ bn_rstd,
+                                                          float* __restrict__ stats) {
   constexpr int C = 128, VEC = Tr<T>::VEC, CH = C / VEC, RPP = 256 / CH;
   __shared__ float ka[128], kb[128];
+  __shared__ float red[RPP][C][2];
   const int tid = threadIdx.x, b = blockIdx.y, l0 = blockIdx.x * SA_WAVE * 4;
   if (tid < 128) {
     const float dm = dpooled[(size_t)b * 256 + tid], ds = dpooled[(size_t)b * 256 + 128 + tid];
@@ -140,34 +147,64 @@ __global__ __launch_bounds__(256) void sa_pool_bwd_kernel(const T* __restrict__ 
     s[j] = sc[c * VEC + j]; t[j] = sh[c * VEC + j];
     jb[j] = (int)(((long long)(c * VEC + j) * L) % 128);
   }
+  float bm[VEC], br[VEC], s1[VEC], s2[VEC];
+#pragma unroll
+  for (int j = 0; j < VEC; ++j) {
+    bm[j] = stats ? bn_mean[c * VEC + j] : 0.0f;
+    br[j] = stats ? bn_rstd[c * VEC + j] : 0.0f;
+    s1[j] = 0.0f; s2[j] = 0.0f;
+  }
   for (int rr = r0; rr < 256; rr += RPP) {
     const int l = l0 + rr;
     if (l >= L) break;
-    float f[VEC];
-    Tr<T>::unpack(*reinterpret_cast<const uint4*>(r + ((size_t)b * L + l) * C + c * VEC), f);
+    float f[VEC], x[VEC];
+    Tr<T>::unpack(*reinterpret_cast<const uint4*>(r + ((size_t)b * L + l) * C + c * VEC), x);
 #pragma unroll
     for (int j = 0; j < VEC; ++j) {
       const int col = (jb[j] + l) % 128;
-      f[j] = fmaf(kb[col], fmaf(f[j], s[j], t[j]), ka[col]);
+      f[j] = fmaf(kb[col], fmaf(x[j], s[j], t[j]), ka[col]);
     }
-    *reinterpret_cast<uint4*>(g + ((size_t)b * L + l) * C + c * VEC) = Tr<T>::pack(f);
+    const uint4 u = Tr<T>::pack(f);
+    *reinterpret_cast<uint4*>(g + ((size_t)b * L + l) * C + c * VEC) = u;
+    if (stats) {
+      Tr<T>::unpack(u, f);                             // the stored (rounded) gradient
+#pragma unroll
+      for (int j = 0; j < VEC; ++j) {
+        s1[j] += f[j];
+        s2[j] = fmaf(f[j], (x[j] - bm[j]) * br[j], s2[j]);
+      }
+    }
+  }
+  if (stats) {
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) { red[r0][c * VEC + j][0] = s1[j]; red[r0][c * VEC + j][1] = s2[j]; }
+    __syncthreads();
+    if (tid < C) {
+      float a0 = 0.0f, a1 = 0.0f;
+#pragma unroll
+      for (int q = 0; q < RPP; ++q) { a0 += red[q][tid][0]; a1 += red[q][tid][1]; }
+      float* dst = stats + (((size_t)b * gridDim.x + blockIdx.x) * C + tid) * 2;
+      dst[0] = a0; dst[1] = a1;
+    }
   }
 }
 
 extern "C" int sa_pool_bwd(int dtype, const void* r, const float* scale, const float* shift,
                            const float* dpooled, const float* mean, const float* stdraw, void* g,
-                           int B, int L, void* stream) {
+                           int B, int L, const float* bn_mean, const float* bn_rstd, float* stats,
+                           void* stream) {
   if (!r || !scale || !shift || !dpooled || !mean || !stdraw || !g || L < 2) return -22;
+  if (stats && (!bn_mean || !bn_rstd)) return -22;
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   dim3 grid(sa_div_up(L, 256), B);
   if (dtype == SA_BF16)
     hipLaunchKernelGGL(sa_pool_bwd_kernel<bf16_t>, grid, dim3(256), 0, st,
                        reinterpret_cast<const bf16_t*>(r), scale, shift, dpooled, mean, stdraw,
-                       reinterpret_cast<bf16_t*>(g), L);
+                       reinterpret_cast<bf16_t*>(g), L, bn_mean, bn_rstd, stats);
   else
     hipLaunchKernelGGL(sa_pool_bwd_kernel<float>, grid, dim3(256), 0, st,
                        reinterpret_cast<const float*>(r), scale, shift, dpooled, mean, stdraw,
-                       reinterpret_cast<float*>(g), L);
+                       reinterpret_cast<float*>(g), L, bn_mean, bn_rstd, stats);
   hipError_t e = hipGetLastError();
   return e == hipSuccess ? 0 : -(int)e;
 }

@@ -10,12 +10,20 @@
 
 // y[b][l][c] = bias[c] + sum_k x[b][l+k-7] * w[c][flip ? 14-k : k]      (x, w fp32; y T)
 // Used as encoder.0 forward (flip=0) and as decoder.8 dgrad (x = d recon, flip=1).
+// Backward epilogue (ep_x != null; the decoder.8 dgrad feeds [InstanceNorm -> x*sigmoid(x)]
+// backward): what is stored is g' = y * swish'(z), z = ep_x*ep_s1[b][c] + ep_t1[b][c], and stats
+// becomes (sum g', sum g'*(ep_x - ep_mean[b][c])*ep_rstd[b][c]) -- the sa_ew_stats pass fused in.
 template <typename T>
 __global__ __launch_bounds__(256) void sa_conv1toC_kernel(const float* __restrict__ x,
                                                           const float* __restrict__ w,
                                                           const float* __restrict__ bias,
                                                           T* __restrict__ y, int L, int flip,
-                                                          float* __restrict__ stats, int ntiles) {
+                                                          float* __restrict__ stats, int ntiles,
+                                                          const T* __restrict__ ep_x,
+                                                          const float* __restrict__ ep_s1,
+                                                          const float* __restrict__ ep_t1,
+                                                          const float* __restrict__ ep_mean,
+                                                          const float* __restrict__ ep_rstd) {
   constexpr int VEC = Tr<T>::VEC, CH = SA_C32 / VEC, PPP = 256 / CH, TILE = 512;
   __shared__ float xs[TILE + SA_K15 - 1];
   __shared__ __attribute__((aligned(16))) float ws[SA_K15][SA_C32];
@@ -34,6 +42,13 @@ __global__ __launch_bounds__(256) void sa_conv1toC_kernel(const float* __restric
   float bv[VEC], ssum[VEC], ssq[VEC];
 #pragma unroll
   for (int j = 0; j < VEC; ++j) { bv[j] = bias ? bias[c * VEC + j] : 0.0f; ssum[j] = 0.f; ssq[j] = 0.f; }
+  float es[VEC], et[VEC], em[VEC], er[VEC];
+#pragma unroll
+  for (int j = 0; j < VEC; ++j) {
+    const size_t bc = (size_t)b * SA_C32 + c * VEC + j;
+    es[j] = ep_x ? ep_s1[bc] : 1.0f; et[j] = ep_x ? ep_t1[bc] : 0.0f;
+    em[j] = ep_x ? ep_mean[bc] : 0.0f; er[j] = ep_x ? ep_rstd[bc] : 0.0f;
+  }
   for (int p = p0; p < TILE; p += PPP) {
     const int l = l0 + p;
     if (l >= L) break;
@@ -46,13 +61,23 @@ __global__ __launch_bounds__(256) void sa_conv1toC_kernel(const float* __restric
 #pragma unroll
       for (int j = 0; j < VEC; ++j) acc[j] = fmaf(xv, ws[k][c * VEC + j], acc[j]);
     }
+    float xn[VEC];
+    if (ep_x) {
+      float xv[VEC];
+      Tr<T>::unpack(*reinterpret_cast<const uint4*>(ep_x + ((size_t)b * L + l) * SA_C32 + c * VEC), xv);
+#pragma unroll
+      for (int j = 0; j < VEC; ++j) {
+        acc[j] *= sa_swish_grad(fmaf(xv[j], es[j], et[j]));
+        xn[j] = (xv[j] - em[j]) * er[j];
+      }
+    }
     const uint4 u = Tr<T>::pack(acc);
     *reinterpret_cast<uint4*>(y + ((size_t)b * L + l) * SA_C32 + c * VEC) = u;
     if (stats) {
       float f[VEC];
       Tr<T>::unpack(u, f);
 #pragma unroll
-      for (int j = 0; j < VEC; ++j) { ssum[j] += f[j]; ssq[j] = fmaf(f[j], f[j], ssq[j]); }
+      for (int j = 0; j < VEC; ++j) { ssum[j] += f[j]; ssq[j] = fmaf(f[j], ep_x ? xn[j] : f[j], ssq[j]); }
     }
   }
   if (stats) {
@@ -71,17 +96,22 @@ __global__ __launch_bounds__(256) void sa_conv1toC_kernel(const float* __restric
 extern "C" int sa_conv1toC_ntiles(int L) { return sa_div_up(L, 512); }
 
 extern "C" int sa_conv1toC(int dtype, const float* x, const float* w, const float* bias, void* y,
-                           int B, int L, int flip, float* stats, void* stream) {
+                           int B, int L, int flip, float* stats, const void* ep_x, const float* ep_s1,
+                           const float* ep_t1, const float* ep_mean, const float* ep_rstd,
+                           void* stream) {
   if (!x || !w || !y || B <= 0 || L <= 0) return -22;
+  if (ep_x && (!ep_s1 || !ep_t1 || !ep_mean || !ep_rstd)) return -22;
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   const int nt = sa_div_up(L, 512);
   dim3 grid(nt, B);
   if (dtype == SA_BF16)
     hipLaunchKernelGGL(sa_conv1toC_kernel<bf16_t>, grid, dim3(256), 0, st, x, w, bias,
-                       reinterpret_cast<bf16_t*>(y), L, flip, stats, nt);
+                       reinterpret_cast<bf16_t*>(y), L, flip, stats, nt,
+                       reinterpret_cast<const bf16_t*>(ep_x), ep_s1, ep_t1, ep_mean, ep_rstd);
   else
     hipLaunchKernelGGL(sa_conv1toC_kernel<float>, grid, dim3(256), 0, st, x, w, bias,
-                       reinterpret_cast<float*>(y), L, flip, stats, nt);
+                       reinterpret_cast<float*>(y), L, flip, stats, nt,
+                       reinterpret_cast<const float*>(ep_x), ep_s1, ep_t1, ep_mean, ep_rstd);
   hipError_t e = hipGetLastError();
   return e == hipSuccess ? 0 : -(int)e;
 }

@@ -213,14 +213,17 @@ def wgrad(x, dy, cin, cout, sa, u, taps, Mrows, dst, dst_strides, s1=None, t1=No
     return dst
 
 
-def conv1toC(x, w, bias, dtype, flip=False, want_stats=False):
+def conv1toC(x, w, bias, dtype, flip=False, want_stats=False, ep=None):
+    """ep=dict(x=, s1=, t1=, mean=, rstd=): fused [InstanceNorm -> x*sigmoid(x)] backward epilogue."""
     lib = L.load()
     B, Ln = x.shape
     y = torch.empty(B, Ln, 32, dtype=dtype, device=x.device)
     nt = lib.sa_conv1toC_ntiles(Ln)
     stats = torch.empty(B, nt, 32, 2, dtype=torch.float32, device=x.device) if want_stats else None
+    e = ep or {}
     L.check(lib.sa_conv1toC(L.dt_code(dtype), _f(x), _f(w), _f(bias), _f(y), B, Ln, int(flip),
-                            _f(stats), L.stream()), "sa_conv1toC")
+                            _f(stats), _f(e.get("x")), _f(e.get("s1")), _f(e.get("t1")),
+                            _f(e.get("mean")), _f(e.get("rstd")), L.stream()), "sa_conv1toC")
     return (y, stats) if want_stats else y
 
 
@@ -350,13 +353,17 @@ def pool_fwd(r, scale, shift, noise=None, eps=1e-5):
     return pooled, mean, sd
 
 
-def pool_bwd(r, scale, shift, dpooled, mean, sd):
+def pool_bwd(r, scale, shift, dpooled, mean, sd, bn=None):
+    """bn=(mean[128], rstd[128]) of the BatchNorm that produced the pooled tensor: also return the
+    partial (sum g, sum g*xhat) slabs [B, ntiles, 128, 2] of its backward."""
     lib = L.load()
     B, Ln, _ = r.shape
     g = torch.empty_like(r)
+    st = torch.empty(B, -(-Ln // 256), 128, 2, dtype=torch.float32, device=r.device) if bn else None
     L.check(lib.sa_pool_bwd(L.dt_code(r.dtype), _f(r), _f(scale), _f(shift), _f(dpooled), _f(mean),
-                            _f(sd), _f(g), B, Ln, L.stream()), "sa_pool_bwd")
-    return g
+                            _f(sd), _f(g), B, Ln, _f(bn[0]) if bn else None, _f(bn[1]) if bn else None,
+                            _f(st), L.stream()), "sa_pool_bwd")
+    return (g, st) if bn else g
 
 
 def dense(X, W, bias, N, K, ps=None, pt=None, relu=False, transpose_w=False):

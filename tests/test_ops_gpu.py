@@ -179,6 +179,17 @@ def test_small_channel_kernels(dt):
     torch.cuda.synchronize()
     assert rel_mse(uncl(gad), ga) < tol(dt)
     assert rel_mse(gw8d, gw8) < 1e-9
+    # the same dgrad with the fused [InstanceNorm -> swish] backward epilogue == dgrad + sa_ew_stats
+    mu, rs = 0.1 * rnd(torch.float32, B, 32, seed=21).to(dev()), (1 + 0.1 * rnd(torch.float32, B, 32, seed=22)).abs().to(dev())
+    vd = cl(v, dt)
+    gz, st = ops.conv1toC(g8[:, 0].contiguous().to(dev()), w8.to(dev()), None, dt, flip=True, want_stats=True,
+                          ep=dict(x=vd, s1=s1.to(dev()), t1=t1.to(dev()), mean=mu, rstd=rs))
+    gz_ref = torch.empty_like(gad)
+    st_ref = ops.ew("stats", gad, vd, 32, out=gz_ref, s1=s1.to(dev()), t1=t1.to(dev()), mean=mu, rstd=rs,
+                    actbwd=True)
+    torch.cuda.synchronize()
+    assert rel_mse(gz.float(), gz_ref.float()) < tol(dt)
+    assert rel_mse(ops.sum_partials(st, B).cpu(), ops.sum_partials(st_ref, B).cpu()) < (1e-10 if dt == torch.float32 else 1e-4)
 
 
 @pytest.mark.parametrize("dt", DT)
@@ -282,6 +293,13 @@ def test_statistics_pooling_reshape_quirk(dt, Ln):
     torch.cuda.synchronize()
     assert rel_mse(pd, pooled.detach()) < 1e-9
     assert rel_mse(uncl(g), gx) < (1e-9 if dt == torch.float32 else 2e-5)
+    # fused BatchNorm-backward statistics of the written gradient == a separate sa_ew_stats pass
+    bm, br = 0.1 * rnd(torch.float32, Cc, seed=45).to(dev()), (1 + 0.1 * rnd(torch.float32, Cc, seed=46)).abs().to(dev())
+    g2, st = ops.pool_bwd(rd, sc.to(dev()), sh.to(dev()), gp.to(dev()), mean, sd, bn=(bm, br))
+    st_ref = ops.ew("stats", g, rd, Cc, mean=bm, rstd=br, per_c=True)
+    assert torch.equal(g2, g)
+    a, b_ = ops.sum_partials(st, 1).cpu(), ops.sum_partials(st_ref, 1).cpu()
+    assert rel_mse(a, b_) < (1e-10 if dt == torch.float32 else 1e-6)
     # noise term of speechbrain's pooling: mean += eps*((1-9)*g+9)
     noise = torch.rand(B, 128)
     pn, _, _ = ops.pool_fwd(rd, sc.to(dev()), sh.to(dev()), noise=noise.to(dev()))
