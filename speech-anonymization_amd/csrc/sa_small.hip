@@ -198,8 +198,13 @@ extern "C" int sa_convCto1(int dtype, const void* x, const float* w, const float
 
 // slab[wg][c][k] = sum_{l in chunk} u[b][l + kk - 7] * P(v[b][l][c]),  kk = flip ? 14-k : k
 // encoder.0 wgrad: u = feats, v = d y0 (flip 0);  decoder.8 wgrad: u = d recon, v = y8 with the
-// InstanceNorm+swish prologue (flip 1).  Also slab[wg][480 + c] = sum_l P(v)[l][c] is NOT
-// produced here; bias gradients come from the per-(b,c) sums of the producing kernels.
+// InstanceNorm+swish prologue (flip 1).  Bias gradients come from the per-(b,c) sums of the
+// producing kernels.
+// A [taps x positions] x [positions x channels] GEMM on the exact-fp32 MFMA
+// (v_mfma_f32_16x16x4_f32): A[m][q] = u[q + kk(m)] is read straight from the staged u row (a
+// Toeplitz operand needs no copy), B[q][c] = P(v)[q][c] from the staged tile.  Each wave owns 64
+// of the tile's 256 positions; k-slot j of step t is position t + 16*j, which puts the four rows
+// of a B fragment 16*33 floats apart = disjoint 16-bank windows (pitch 33).
 template <typename T>
 __global__ __launch_bounds__(256) void sa_wgrad1C_kernel(const float* __restrict__ u,
                                                          const T* __restrict__ v,
@@ -208,9 +213,9 @@ __global__ __launch_bounds__(256) void sa_wgrad1C_kernel(const float* __restrict
                                                          const float* __restrict__ s1,
                                                          const float* __restrict__ t1, int swish) {
   constexpr int VEC = Tr<T>::VEC, CH = SA_C32 / VEC, RPP = 256 / CH, TILE = 256, PITCH = 33;
-  __shared__ float us[TILE + SA_K15 - 1];
+  __shared__ float us[TILE + SA_K15 - 1 + 1];
   __shared__ float vs[TILE * PITCH];
-  const int tid = threadIdx.x, b = blockIdx.y;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, b = blockIdx.y;
   const int lbeg = blockIdx.x * chunk;
   int lend = lbeg + chunk; if (lend > L) lend = L;
   const int c = tid % CH, r0 = tid / CH;
@@ -221,49 +226,73 @@ __global__ __launch_bounds__(256) void sa_wgrad1C_kernel(const float* __restrict
     sh[j] = t1 ? t1[(size_t)b * SA_C32 + c * VEC + j] : 0.0f;
   }
   const bool tr_on = (s1 != nullptr) || swish;
-  // thread -> (tap k, channel pair)
-  const int k = tid % SA_K15, cp = tid / SA_K15;           // cp < 16 for tid < 240
-  const int kk = flip ? SA_K15 - 1 - k : k;
-  float a0 = 0.0f, a1 = 0.0f;
-  for (int l0 = lbeg; l0 < lend; l0 += TILE) {
-    for (int i = tid; i < TILE + SA_K15 - 1; i += 256) {
-      const int g = l0 + i - 7;
-      us[i] = (g >= 0 && g < L) ? u[(size_t)b * L + g] : 0.0f;
+  const int m = lane & 15, j4 = lane >> 4;                 // MFMA row (tap) / k-slot of this lane
+  const bool mval = m < SA_K15;
+  const int kk = mval ? (flip ? SA_K15 - 1 - m : m) : 0;
+  const int qa = wave * 64 + 16 * j4;                      // first position of this lane's k-slot
+  f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+  // the rows of tile i+1 are in flight (registers) while tile i is staged and multiplied
+  constexpr int NIT = TILE / RPP, NU = (TILE + SA_K15 - 1 + 255) / 256;
+  uint4 raw[NIT];
+  float rawu[NU];
+  auto issue = [&](int l0) {
+#pragma unroll
+    for (int i = 0; i < NIT; ++i) {
+      const int g = l0 + r0 + i * RPP;
+      raw[i] = make_uint4(0, 0, 0, 0);
+      if (g < lend) raw[i] = *reinterpret_cast<const uint4*>(v + ((size_t)b * L + g) * SA_C32 + c * VEC);
     }
-    for (int r = r0; r < TILE; r += RPP) {
-      const int g = l0 + r;
+#pragma unroll
+    for (int i = 0; i < NU; ++i) {
+      const int g = l0 + tid + i * 256 - 7;
+      rawu[i] = (l0 < lend && tid + i * 256 < TILE + SA_K15 - 1 && g >= 0 && g < L) ? u[(size_t)b * L + g] : 0.0f;
+    }
+  };
+  issue(lbeg);
+  for (int l0 = lbeg; l0 < lend; l0 += TILE) {
+#pragma unroll
+    for (int i = 0; i < NU; ++i)
+      if (tid + i * 256 < TILE + SA_K15 - 1) us[tid + i * 256] = rawu[i];
+#pragma unroll
+    for (int i = 0; i < NIT; ++i) {
+      const int r = r0 + i * RPP, g = l0 + r;
       float f[VEC];
+      Tr<T>::unpack(raw[i], f);
+      if (tr_on && g < lend) {
 #pragma unroll
-      for (int j = 0; j < VEC; ++j) f[j] = 0.0f;
-      if (g < lend) {
-        const uint4 q = *reinterpret_cast<const uint4*>(v + ((size_t)b * L + g) * SA_C32 + c * VEC);
-        Tr<T>::unpack(q, f);
-        if (tr_on) {
-#pragma unroll
-          for (int j = 0; j < VEC; ++j) {
-            float z = fmaf(f[j], sc[j], sh[j]);
-            f[j] = swish ? sa_swish(z) : z;
-          }
+        for (int j = 0; j < VEC; ++j) {
+          float z = fmaf(f[j], sc[j], sh[j]);
+          f[j] = swish ? sa_swish(z) : z;
         }
       }
 #pragma unroll
       for (int j = 0; j < VEC; ++j) vs[r * PITCH + c * VEC + j] = f[j];
     }
     __syncthreads();
-    if (tid < SA_K15 * 16) {
-#pragma unroll 8
-      for (int p = 0; p < TILE; ++p) {
-        const float uv = us[p + kk];
-        a0 = fmaf(uv, vs[p * PITCH + 2 * cp], a0);
-        a1 = fmaf(uv, vs[p * PITCH + 2 * cp + 1], a1);
-      }
+    issue(l0 + TILE);
+#pragma unroll 4
+    for (int t = 0; t < 16; ++t) {
+      const int q = qa + t;
+      const float av = mval ? us[q + kk] : 0.0f;
+      const float b0 = vs[q * PITCH + m], b1 = vs[q * PITCH + 16 + m];
+      acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av, b0, acc0, 0, 0, 0);
+      acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av, b1, acc1, 0, 0, 0);
     }
     __syncthreads();
   }
-  if (tid < SA_K15 * 16) {
-    float* slab = slabs + ((size_t)b * gridDim.x + blockIdx.x) * (SA_C32 * SA_K15);
-    slab[(2 * cp) * SA_K15 + k] = a0;
-    slab[(2 * cp + 1) * SA_K15 + k] = a1;
+  // D[tap = 4*(lane>>4) + i][channel = nt*16 + (lane&15)]: add the four waves' partials in wave order
+  float* part = vs;                                        // [4][16][32]
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    part[(wave * 16 + 4 * j4 + i) * 32 + m] = acc0[i];
+    part[(wave * 16 + 4 * j4 + i) * 32 + 16 + m] = acc1[i];
+  }
+  __syncthreads();
+  for (int o = tid; o < SA_K15 * SA_C32; o += 256) {
+    const int k = o / SA_C32, cc = o % SA_C32;
+    const float sum = ((part[(0 * 16 + k) * 32 + cc] + part[(1 * 16 + k) * 32 + cc]) +
+                       part[(2 * 16 + k) * 32 + cc]) + part[(3 * 16 + k) * 32 + cc];
+    slabs[((size_t)b * gridDim.x + blockIdx.x) * (SA_C32 * SA_K15) + cc * SA_K15 + k] = sum;
   }
 }
 
