@@ -209,8 +209,11 @@ int sa_cluster_mi(const float* X, const long long* y, const long long* idx, int 
 
 /* ---- feature front-end (sa_fbank.hip): speechbrain Fbank + InputNormalization at
  * speechbrain_convae_train.py:58-63,82-87 (convae.yaml:93-95,269-271,289-292) --------- */
-int sa_fbank(const float* wav, int B, int N, const float* window, const float* dft,
-             const float* mel, float* feats, float* tilemax, void* stream);
+/* dft / mel: bf16 fragment-major operand images built once by the host (layout in sa_fbank.hip;
+ * speech-anonymization_amd/features.py builds them), sa_fbank_table_elems(0 | 1) elements each */
+int sa_fbank(const float* wav, int B, int N, const float* window, const void* dft,
+             const void* mel, float* feats, float* tilemax, void* stream);
+int sa_fbank_table_elems(int which);
 int sa_fbank_ntiles(int T);
 int sa_fbank_scratch_bytes(int B);
 int sa_fbank_normalize(const float* feats, const float* tilemax, int B, int T, int Tp,

@@ -5,13 +5,16 @@
 // modules.normalize (speechbrain InputNormalization, norm_type "global",
 // convae.yaml:269-271) at the reference call sites speechbrain_convae_train.py:58-63,82-87.
 //
-// Kernel 1 (sa_fbank_kernel): one workgroup = 32 frames of one utterance.  The 400-sample
-// Hamming-windowed frames (hop 160, centre padding 200 zeros each side) are built in LDS
-// from coalesced waveform loads, multiplied by the [400 x 416] cos|sin DFT table on the exact
-// fp32 MFMA (v_mfma_f32_32x32x2_f32; a bf16 spectrum would put a -48 dB quantisation floor
-// under every frame), squared into the power spectrum in LDS, multiplied by the [208 x 96]
-// padded Mel matrix on the same MFMA, and written as 10*log10(max(.,1e-10)) with the
-// per-tile maximum for the top-dB clamp.
+// Kernel 1 (sa_fbank_kernel): one workgroup = 32 frames of one utterance.  The real-input DFT
+// is folded: with e[k] = x[k] + x[400-k], o[k] = x[k] - x[400-k] (k = 1..199; e[0] = x[0],
+// e[200] = x[200]) the spectrum is re = e . cos, im = o . sin over k = 0..200 -- half the
+// multiplies and half the table of the direct [400 x 402] product.  Both GEMMs run on the bf16
+// MFMA with split operands: the DFT with a 3-way split (h + m + l = 24 significant bits per
+// operand, the six products down to 2^-24 are kept: hh, hm, mh, hl, lh, mm -- fp32-class
+// accuracy, a plain bf16 spectrum would put a -48 dB quantisation floor under every frame), the
+// all-positive Mel product with the 2-way split of the conv kernels.  Frames are built in LDS
+// from coalesced waveform loads, the power spectrum overlays them, and the result is written as
+// 10*log10(max(.,1e-10)) with the per-tile maximum for the top-dB clamp.
 // Kernel 2/3: per-utterance clamp floor + length-masked mean / unbiased std per Mel bin;
 // running global statistics; (x - glob_mean)/glob_std with zero rows appended up to T'.
 #include "sa_common.h"
@@ -19,71 +22,148 @@
 #define SA_NFFT 400
 #define SA_HOP 160
 #define SA_NBIN 201
-#define SA_DFT_COLS 416      // 13 tiles x (16 cos | 16 sin)
-#define SA_MEL_ROWS 208
-#define SA_MEL_COLS 96
+#define SA_FK 208            // folded reduction length (201 used), 13 k-steps of 16
+#define SA_FKS 13
+#define SA_BINT 7            // 32-bin tiles (224 columns, 201 used)
+#define SA_MELT 3            // 32-column Mel tiles (96 columns, 80 used)
 #define SA_NMEL 80
 #define SA_FB_FRAMES 32
 
+// v = h + m + l with h, m, l bf16 (24 significant bits)
+__device__ static inline void sa_split3(float v, bf16_t& h, bf16_t& m, bf16_t& l) {
+  h = (bf16_t)v;
+  const float r1 = v - (float)h;
+  m = (bf16_t)r1;
+  l = (bf16_t)(r1 - (float)m);
+}
+
+// dft: fragment-major bf16 image [cos|sin][h|m|l][13 k-steps][7 bin tiles][64 lanes][8], element
+//      (k = ks*16 + 8*(lane>>5) + j, bin = q*32 + (lane&31)); mel: [h|l][13][3][64][8] likewise
+//      (k = frequency bin, column = Mel filter).  Built once by the host (features.py).
 __global__ __launch_bounds__(256) void sa_fbank_kernel(const float* __restrict__ wav, int N, int T,
                                                        const float* __restrict__ window,
-                                                       const float* __restrict__ dft,
-                                                       const float* __restrict__ mel,
+                                                       const bf16x8* __restrict__ dft,
+                                                       const bf16x8* __restrict__ mel,
                                                        float* __restrict__ feats,
                                                        float* __restrict__ tilemax, int ntiles) {
-  constexpr int APITCH = 401, PPITCH = 209;
+  constexpr int PL = SA_FB_FRAMES * SA_FK;                        // elements per plane
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  float* As = reinterpret_cast<float*>(smem);                    // [32][401] windowed frames
-  float* Ps = As + SA_FB_FRAMES * APITCH;                        // [32][209] power spectrum
-  float* wmax = Ps + SA_FB_FRAMES * PPITCH;                      // [4]
+  bf16_t* E = reinterpret_cast<bf16_t*>(smem);                    // [3][32][208] even part
+  bf16_t* O = E + 3 * PL;                                         // [3][32][208] odd part
+  bf16_t* P = E;                                                  // [2][32][208] power (overlay)
+  __shared__ float wmax[4];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int b = blockIdx.y, t0 = blockIdx.x * SA_FB_FRAMES;
   const float* wb = wav + (size_t)b * N;
-  for (int i = tid; i < SA_FB_FRAMES * SA_NFFT; i += 256) {
-    const int m = i / SA_NFFT, k = i % SA_NFFT;
-    const int n = (t0 + m) * SA_HOP + k - SA_NFFT / 2;
-    float v = 0.0f;
-    if (t0 + m < T && n >= 0 && n < N) v = wb[n] * window[k];
-    As[m * APITCH + k] = v;
+  // ---- folded, windowed frames -> split planes (two k per thread and step) ----
+  for (int i = tid; i < SA_FB_FRAMES * (SA_FK / 2); i += 256) {
+    const int m = i / (SA_FK / 2), k0 = 2 * (i % (SA_FK / 2));
+    const int base = (t0 + m) * SA_HOP - SA_NFFT / 2;
+    bf16_t eh[2], em[2], el[2], oh[2], om[2], ol[2];
+#pragma unroll
+    for (int d = 0; d < 2; ++d) {
+      const int k = k0 + d;
+      float xk = 0.0f, xr = 0.0f;
+      if (t0 + m < T && k <= SA_NFFT / 2) {
+        const int n1 = base + k, n2 = base + SA_NFFT - k;
+        if (n1 >= 0 && n1 < N) xk = wb[n1] * window[k];
+        if (k >= 1 && k < SA_NFFT / 2 && n2 >= 0 && n2 < N) xr = wb[n2] * window[SA_NFFT - k];
+      }
+      sa_split3(xk + xr, eh[d], em[d], el[d]);
+      sa_split3(xk - xr, oh[d], om[d], ol[d]);
+    }
+    const int at = m * SA_FK + k0;
+    auto put2 = [&](bf16_t* dst, const bf16_t* v) { dst[0] = v[0]; dst[1] = v[1]; };
+    put2(E + at, eh); put2(E + PL + at, em); put2(E + 2 * PL + at, el);
+    put2(O + at, oh); put2(O + PL + at, om); put2(O + 2 * PL + at, ol);
   }
-  for (int i = tid; i < SA_FB_FRAMES * PPITCH; i += 256) Ps[i] = 0.0f;
   __syncthreads();
-  // ---- GEMM 1: [32 x 400] x [400 x 416] -> re | im, squared into Ps ----
-  for (int q = wave; q < SA_DFT_COLS / 32; q += 4) {
-    f32x16 acc;
+  // ---- GEMM 1: re = e . cos, im = o . sin; bin tiles q = wave, wave + 4 ----
+  f32x16 pw[2];
+  const int arow = (lane & 31) * SA_FK + 8 * (lane >> 5);
 #pragma unroll
-    for (int i = 0; i < 16; ++i) acc[i] = 0.0f;
-    const float* ap = As + (lane & 31) * APITCH + (lane >> 5);
-    const float* bp = dft + (size_t)(lane >> 5) * SA_DFT_COLS + q * 32 + (lane & 31);
-#pragma unroll 8
-    for (int k0 = 0; k0 < SA_NFFT; k0 += 2)
-      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ap[k0], bp[(size_t)k0 * SA_DFT_COLS], acc, 0, 0, 0);
+  for (int qi = 0; qi < 2; ++qi) {
+    const int q = wave + 4 * qi;
 #pragma unroll
-    for (int i = 0; i < 16; ++i) {
-      const float sq = acc[i] * acc[i];
-      const float pw = sq + __shfl_xor(sq, 16, 64);
-      const int bin = q * 16 + (lane & 15);
-      if ((lane & 16) == 0 && bin < SA_NBIN) Ps[sa_acc_row(i, lane) * PPITCH + bin] = pw;
+    for (int i = 0; i < 16; ++i) pw[qi][i] = 0.0f;
+    if (q < SA_BINT) {
+      f32x16 cm, cs, sm, ss;                                       // main (h*h) and small-term sums
+#pragma unroll
+      for (int i = 0; i < 16; ++i) { cm[i] = 0.0f; cs[i] = 0.0f; sm[i] = 0.0f; ss[i] = 0.0f; }
+      const bf16x8* ct = dft + (size_t)q * 64 + lane;
+      constexpr size_t PLANE = (size_t)SA_FKS * SA_BINT * 64;      // fragments per table plane
+#pragma unroll 2
+      for (int ks = 0; ks < SA_FKS; ++ks) {
+        const bf16x8* cp = ct + (size_t)ks * SA_BINT * 64;
+        const bf16x8 ch = cp[0], cmm = cp[PLANE], cl = cp[2 * PLANE];
+        const bf16x8 sh = cp[3 * PLANE], smm = cp[4 * PLANE], sl = cp[5 * PLANE];
+        const bf16_t* ap = E + arow + ks * 16;
+        const bf16x8 eh = *reinterpret_cast<const bf16x8*>(ap);
+        const bf16x8 em = *reinterpret_cast<const bf16x8*>(ap + PL);
+        const bf16x8 el = *reinterpret_cast<const bf16x8*>(ap + 2 * PL);
+        const bf16x8 oh = *reinterpret_cast<const bf16x8*>(ap + 3 * PL);
+        const bf16x8 om = *reinterpret_cast<const bf16x8*>(ap + 4 * PL);
+        const bf16x8 ol = *reinterpret_cast<const bf16x8*>(ap + 5 * PL);
+        cs = __builtin_amdgcn_mfma_f32_32x32x16_bf16(em, cmm, cs, 0, 0, 0);
+        cs = __builtin_amdgcn_mfma_f32_32x32x16_bf16(el, ch, cs, 0, 0, 0);
+        cs = __builtin_amdgcn_mfma_f32_32x32x16_bf16(eh, cl, cs, 0, 0, 0);
+        cs = __builtin_amdgcn_mfma_f32_32x32x16_bf16(em, ch, cs, 0, 0, 0);
+        cs = __builtin_amdgcn_mfma_f32_32x32x16_bf16(eh, cmm, cs, 0, 0, 0);
+        cm = __builtin_amdgcn_mfma_f32_32x32x16_bf16(eh, ch, cm, 0, 0, 0);
+        ss = __builtin_amdgcn_mfma_f32_32x32x16_bf16(om, smm, ss, 0, 0, 0);
+        ss = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ol, sh, ss, 0, 0, 0);
+        ss = __builtin_amdgcn_mfma_f32_32x32x16_bf16(oh, sl, ss, 0, 0, 0);
+        ss = __builtin_amdgcn_mfma_f32_32x32x16_bf16(om, sh, ss, 0, 0, 0);
+        ss = __builtin_amdgcn_mfma_f32_32x32x16_bf16(oh, smm, ss, 0, 0, 0);
+        sm = __builtin_amdgcn_mfma_f32_32x32x16_bf16(oh, sh, sm, 0, 0, 0);
+      }
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const float re = cm[i] + cs[i], im = sm[i] + ss[i];
+        pw[qi][i] = fmaf(re, re, im * im);
+      }
+    }
+  }
+  __syncthreads();                                   // every wave is done with E / O
+  // ---- power spectrum -> hi / lo planes (bins >= 201 are exact zeros: zero table columns) ----
+#pragma unroll
+  for (int qi = 0; qi < 2; ++qi) {
+    const int bin = (wave + 4 * qi) * 32 + (lane & 31);
+    if (wave + 4 * qi < SA_BINT && bin < SA_FK) {
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const bf16_t h = (bf16_t)pw[qi][i];
+        const int at = sa_acc_row(i, lane) * SA_FK + bin;
+        P[at] = h;
+        P[PL + at] = (bf16_t)(pw[qi][i] - (float)h);
+      }
     }
   }
   __syncthreads();
   // ---- GEMM 2: [32 x 208] x [208 x 96] -> Mel energies -> dB ----
   float mx = -INFINITY;
-  if (wave < SA_MEL_COLS / 32) {
-    f32x16 acc;
+  if (wave < SA_MELT) {
+    f32x16 am, as;
 #pragma unroll
-    for (int i = 0; i < 16; ++i) acc[i] = 0.0f;
-    const float* ap = Ps + (lane & 31) * PPITCH + (lane >> 5);
-    const float* bp = mel + (size_t)(lane >> 5) * SA_MEL_COLS + wave * 32 + (lane & 31);
-#pragma unroll 8
-    for (int k0 = 0; k0 < SA_MEL_ROWS; k0 += 2)
-      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ap[k0], bp[(size_t)k0 * SA_MEL_COLS], acc, 0, 0, 0);
+    for (int i = 0; i < 16; ++i) { am[i] = 0.0f; as[i] = 0.0f; }
+    constexpr size_t MPLANE = (size_t)SA_FKS * SA_MELT * 64;
+#pragma unroll 2
+    for (int ks = 0; ks < SA_FKS; ++ks) {
+      const bf16x8* mp = mel + ((size_t)ks * SA_MELT + wave) * 64 + lane;
+      const bf16x8 mh = mp[0], ml = mp[MPLANE];
+      const bf16_t* ap = P + arow + ks * 16;
+      const bf16x8 ph = *reinterpret_cast<const bf16x8*>(ap);
+      const bf16x8 pl = *reinterpret_cast<const bf16x8*>(ap + PL);
+      as = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pl, mh, as, 0, 0, 0);
+      as = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ph, ml, as, 0, 0, 0);
+      am = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ph, mh, am, 0, 0, 0);
+    }
     const int col = wave * 32 + (lane & 31);
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
       const int t = t0 + sa_acc_row(i, lane);
       if (col < SA_NMEL && t < T) {
-        const float db = 10.0f * log10f(fmaxf(acc[i], 1e-10f));
+        const float db = 10.0f * log10f(fmaxf(am[i] + as[i], 1e-10f));
         feats[((size_t)b * T + t) * SA_NMEL + col] = db;
         mx = fmaxf(mx, db);
       }
@@ -99,12 +179,16 @@ __global__ __launch_bounds__(256) void sa_fbank_kernel(const float* __restrict__
 extern "C" int sa_fbank_ntiles(int T) { return sa_div_up(T, SA_FB_FRAMES); }
 
 // feats: [B][T][80] raw dB (T = 1 + N/160); tilemax: [B][ntiles]
-extern "C" int sa_fbank(const float* wav, int B, int N, const float* window, const float* dft,
-                        const float* mel, float* feats, float* tilemax, void* stream) {
+extern "C" int sa_fbank_table_elems(int which) {       // bf16 elements of the dft (0) / mel (1) image
+  return which == 0 ? 2 * 3 * SA_FKS * SA_BINT * 64 * 8 : 2 * SA_FKS * SA_MELT * 64 * 8;
+}
+
+extern "C" int sa_fbank(const float* wav, int B, int N, const float* window, const void* dft,
+                        const void* mel, float* feats, float* tilemax, void* stream) {
   if (!wav || !window || !dft || !mel || !feats || !tilemax || B <= 0 || N <= 0) return -22;
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   const int T = 1 + N / SA_HOP, nt = sa_div_up(T, SA_FB_FRAMES);
-  const size_t lds = (size_t)(SA_FB_FRAMES * 401 + SA_FB_FRAMES * 209 + 4) * sizeof(float);
+  const size_t lds = (size_t)6 * SA_FB_FRAMES * SA_FK * sizeof(bf16_t);
   static bool attr = false;
   if (!attr) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(sa_fbank_kernel),
@@ -112,8 +196,9 @@ extern "C" int sa_fbank(const float* wav, int B, int N, const float* window, con
     if (e != hipSuccess) return -(int)e;
     attr = true;
   }
-  hipLaunchKernelGGL(sa_fbank_kernel, dim3(nt, B), dim3(256), lds, st, wav, N, T, window, dft, mel,
-                     feats, tilemax, nt);
+  hipLaunchKernelGGL(sa_fbank_kernel, dim3(nt, B), dim3(256), lds, st, wav, N, T, window,
+                     reinterpret_cast<const bf16x8*>(dft), reinterpret_cast<const bf16x8*>(mel), feats,
+                     tilemax, nt);
   hipError_t e = hipGetLastError();
   return e == hipSuccess ? 0 : -(int)e;
 }

@@ -19,7 +19,7 @@ import torch
 
 from . import _lib as L
 
-N_FFT, HOP, NBIN, DFT_COLS, MEL_ROWS, MEL_COLS = 400, 160, 201, 416, 208, 96
+N_FFT, HOP, NBIN, FK, KSTEPS, BIN_TILES, MEL_ROWS, MEL_COLS = 400, 160, 201, 208, 13, 7, 208, 96
 
 
 def _hamming(n):
@@ -27,18 +27,41 @@ def _hamming(n):
     return (0.54 - 0.46 * np.cos(2.0 * np.pi * i / n)).astype(np.float32)      # periodic
 
 
-def _dft_table():
-    """[400][416]: tile q holds cos of bins 16q..16q+15 then sin of the same bins."""
-    k = np.arange(N_FFT, dtype=np.float64)[:, None]
-    tab = np.zeros((N_FFT, DFT_COLS), dtype=np.float64)
-    for q in range(DFT_COLS // 32):
-        for j in range(16):
-            b = 16 * q + j
-            if b < NBIN:
-                ang = 2.0 * np.pi * ((k[:, 0] * b) % N_FFT) / N_FFT
-                tab[:, 32 * q + j] = np.cos(ang)
-                tab[:, 32 * q + 16 + j] = np.sin(ang)
-    return tab.astype(np.float32)
+def _split_bf16(v, planes):
+    """fp32 tensor -> `planes` bf16 tensors whose sum reproduces it to 8*planes bits (RNE)."""
+    out, r = [], v.float()
+    for _ in range(planes):
+        h = r.to(torch.bfloat16)
+        out.append(h)
+        r = r - h.float()
+    return out
+
+
+def _fragment_image(mat):
+    """[K][N] (K % 16 == 0, N % 32 == 0) -> fragment-major [K/16][N/32][64 lanes][8]: element
+    (k = ks*16 + 8*(lane>>5) + j, n = q*32 + (lane&31)) -- the B operand of v_mfma_f32_32x32x16_bf16."""
+    K, N = mat.shape
+    m = mat.reshape(K // 16, 2, 8, N // 32, 32)          # ks, lane>>5, j, q, lane&31
+    return m.permute(0, 3, 1, 4, 2).contiguous()         # ks, q, lane>>5, lane&31, j
+
+
+def _dft_image():
+    """Folded real DFT tables cos / sin(2 pi k b / 400), k = 0..200 (rows up to 208 zero), b = 0..200
+    (columns up to 224 zero), each split 3-way into bf16: [cos|sin][h|m|l][13][7][64][8]."""
+    k = np.arange(FK, dtype=np.float64)[:, None]
+    b = np.arange(BIN_TILES * 32, dtype=np.float64)[None, :]
+    ang = 2.0 * np.pi * ((k * b) % N_FFT) / N_FFT
+    valid = (k <= N_FFT // 2) & (b < NBIN)
+    tabs = []
+    for f in (np.cos, np.sin):
+        t = torch.from_numpy(np.where(valid, f(ang), 0.0).astype(np.float32))
+        tabs.append(torch.stack([_fragment_image(p) for p in _split_bf16(t, 3)]))
+    return torch.stack(tabs).reshape(-1)
+
+
+def _mel_image(mel):
+    """padded Mel matrix [208][96] fp32 -> [h|l][13][3][64][8] bf16."""
+    return torch.stack([_fragment_image(p) for p in _split_bf16(mel, 2)]).reshape(-1)
 
 
 def _mel_matrix(n_mels, n_fft, sample_rate, f_min=0.0, f_max=None):
@@ -87,8 +110,8 @@ class Fbank(torch.nn.Module):
                                "(speechbrain_configs/convae.yaml:93-95)")
         self.top_db, self.batch_max = float(top_db), top_db_mode != "utterance"
         self.register_buffer("window", torch.from_numpy(_hamming(N_FFT)), persistent=False)
-        self.register_buffer("dft", torch.from_numpy(_dft_table()), persistent=False)
-        self.register_buffer("mel", _mel_matrix(n_mels, n_fft, sample_rate), persistent=False)
+        self.register_buffer("dft", _dft_image(), persistent=False)
+        self.register_buffer("mel", _mel_image(_mel_matrix(n_mels, n_fft, sample_rate)), persistent=False)
 
     @torch.no_grad()
     def forward(self, wav):
