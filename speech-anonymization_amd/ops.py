@@ -169,7 +169,10 @@ def conv_gemm(x, wp, bias, cin, cout, sa, u, phases, Lout, s1=None, t1=None, s2=
     if e0 is not None:
         ntap = sum(len(p) for p in phases)
         esz = x.element_size()
-        PROFILE.stop(e0, (x.numel() + y.numel()) * esz + ntap * cin * cout * esz,
+        extra = (a_out.numel() * 2 if a_out is not None else 0)        # bf16 operand cache written
+        if ep:
+            extra += y.numel() * esz * (2 if ep.get("g2") is not None else 1)   # stored forward tensor (+ 2nd gradient) read
+        PROFILE.stop(e0, (x.numel() + y.numel()) * esz + ntap * cin * cout * esz + extra,
                      2 * B * (-(-Lout // u)) * ntap * cin * cout)
     return (y, stats) if want_stats else y
 
