@@ -72,7 +72,10 @@ struct ConvCfg {
 };
 
 template <typename T, int CIN, int COUT, int SA, int U, int TM>
-__global__ __launch_bounds__(256) void sa_conv_gemm_kernel(SaConvArgs a, int red_off) {
+// (256, 2): with an explicit minimum of resident workgroups hipcc allocates one unified register
+// file (104 registers for 128->128) instead of parking weight fragments in AGPRs behind
+// v_accvgpr_write copies (32 extra instructions per 12 MFMAs in the main loop).
+__global__ __launch_bounds__(256, 2) void sa_conv_gemm_kernel(SaConvArgs a, int red_off) {
   typedef ConvCfg<T, CIN, COUT, SA, U, TM> C;
   typedef Pol<T> P;
   typedef typename P::store_t S;
@@ -119,37 +122,53 @@ __global__ __launch_bounds__(256) void sa_conv_gemm_kernel(SaConvArgs a, int red
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     SA_STAMP(1);                                      // all row loads have landed
 #endif
+    // The transform is selected by kernel arguments, i.e. uniformly: one specialised copy of the
+    // staging loop per case (none: data gradients and ConvT forwards, 13 of 22 launches per step;
+    // affine + x*sigmoid(x): the encoder / decoder forwards; generic) instead of per-element
+    // selects on the flags.
+    auto stage_rows = [&](auto xform) {
 #pragma unroll
-    for (int i = 0; i < NIT; ++i) {
-      const int r = r0 + i * C::RPPI, g = gbase + r;
-      if (r < a.nrows) {
-        float f[VEC];
-        tr::unpack(raw[i], f);
-        if ((has1 || has2 || sw) && g >= 0 && g < a.Lin) {
-#pragma unroll
-          for (int j = 0; j < VEC; ++j) {
-            float v = f[j];
-            if (has1) v = fmaf(v, s1[j], t1[j]);
-            if (sw) v = sa_swish(v);
-            if (has2) v = fmaf(v, s2[j], t2[j]);
-            f[j] = v;
+      for (int i = 0; i < NIT; ++i) {
+        const int r = r0 + i * C::RPPI, g = gbase + r;
+        if (r < a.nrows) {
+          float f[VEC];
+          tr::unpack(raw[i], f);
+          if (g >= 0 && g < a.Lin) xform(f);
+          LT* dst = As + (size_t)r * C::APITCH + c * VEC;
+          if constexpr (P::NPL == 2) {
+            uint2 hi, lo;
+            sa_split4(f, hi, lo);
+            *reinterpret_cast<uint2*>(dst) = hi;
+            *reinterpret_cast<uint2*>(dst + plane) = lo;
+          } else if constexpr (sizeof(LT) == 2 && sizeof(S) == 4) {
+            *reinterpret_cast<uint2*>(dst) = sa_pack_bf16x4(f);
+          } else if constexpr (sizeof(LT) == 2) {
+            *reinterpret_cast<uint4*>(dst) = tr::pack(f);
+          } else {
+            float* d = reinterpret_cast<float*>(dst);
+            d[0] = f[0]; d[1] = f[1]; d[2] = f[2]; d[3] = f[3];
           }
         }
-        LT* dst = As + (size_t)r * C::APITCH + c * VEC;
-        if constexpr (P::NPL == 2) {
-          uint2 hi, lo;
-          sa_split4(f, hi, lo);
-          *reinterpret_cast<uint2*>(dst) = hi;
-          *reinterpret_cast<uint2*>(dst + plane) = lo;
-        } else if constexpr (sizeof(LT) == 2 && sizeof(S) == 4) {
-          *reinterpret_cast<uint2*>(dst) = sa_pack_bf16x4(f);
-        } else if constexpr (sizeof(LT) == 2) {
-          *reinterpret_cast<uint4*>(dst) = tr::pack(f);
-        } else {
-          float* d = reinterpret_cast<float*>(dst);
-          d[0] = f[0]; d[1] = f[1]; d[2] = f[2]; d[3] = f[3];
-        }
       }
+    };
+    if (!has1 && !has2 && !sw) {
+      stage_rows([](float*) {});
+    } else if (has1 && sw && !has2) {
+      stage_rows([&](float* f) {
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) f[j] = sa_swish(fmaf(f[j], s1[j], t1[j]));
+      });
+    } else {
+      stage_rows([&](float* f) {
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) {
+          float v = f[j];
+          if (has1) v = fmaf(v, s1[j], t1[j]);
+          if (sw) v = sa_swish(v);
+          if (has2) v = fmaf(v, s2[j], t2[j]);
+          f[j] = v;
+        }
+      });
     }
   }
   __syncthreads();
