@@ -105,3 +105,27 @@ def test_instance_norm_epilogue_statistics_at_scale():
     yd = y.double()
     assert torch.allclose(sums[..., 0], yd.sum(1), rtol=1e-6, atol=1e-4)
     assert torch.allclose(sums[..., 1], (yd * yd).sum(1), rtol=1e-6, atol=1e-4)
+
+
+def test_bench_size_step_is_deterministic_and_cache_is_transparent():
+    """BASELINE config 2 (B = 32, T = 1008) has no oracle run; properties instead: (1) the same
+    step twice gives the same BITS in every output and gradient (fixed-order slab reductions, no
+    atomics); (2) the bf16 weight-gradient operand cache changes nothing (cache_wgrad_operand=False
+    recomputes the operand in the wgrad kernels: same products, same order)."""
+    from oracle.features import synthetic_feats
+    B, T = 32, 1008
+    feats = synthetic_feats(B, T, seed=5).cuda()
+    gender = (torch.arange(B) % 2).cuda()
+    m = _model("bf16x3")
+    runs = []
+    for cache in (True, True, False):
+        m.cache_wgrad_operand = cache
+        m.zero_grad(set_to_none=True)
+        sd = {k: v.clone() for k, v in m.state_dict().items()}      # BN running buffers advance
+        r, l, g = _step(m, feats, gender)
+        runs.append((r.clone(), l.clone(), {k: v.clone() for k, v in g.items()}))
+        m.load_state_dict(sd)
+    for r, l, g in runs[1:]:
+        assert torch.equal(r, runs[0][0]) and torch.equal(l, runs[0][1])
+        for k in g:
+            assert torch.equal(g[k], runs[0][2][k]), k
