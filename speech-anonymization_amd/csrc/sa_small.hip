@@ -119,6 +119,9 @@ extern "C" int sa_conv1toC(int dtype, const float* x, const float* w, const floa
 // y[b][l] = bias + sum_k sum_c P(x[b][l+k-7][c]) * w[c][k]       (x T, y fp32)
 // P = prologue: v*s1[b][c]+t1[b][c], then x*sigmoid(x) if swish.   decoder.8 forward
 // (flip=0) and encoder.0 dgrad (flip=1: taps reversed).
+// Two steps per 128-output tile (30 KB of LDS: five workgroups per CU overlap each other's loads): Tp[p][k] = sum_c P(x)[p][c] * w[c][k] for the 142 staged
+// positions on the exact-fp32 MFMA (v_mfma_f32_16x16x4_f32: M = positions, N = 16 tap slots,
+// K = 32 channels), then y[l] = sum_k Tp[l + k][k] (15 LDS reads per output instead of 240).
 template <typename T>
 __global__ __launch_bounds__(256) void sa_convCto1_kernel(const T* __restrict__ x,
                                                           const float* __restrict__ w,
@@ -127,10 +130,12 @@ __global__ __launch_bounds__(256) void sa_convCto1_kernel(const T* __restrict__ 
                                                           const float* __restrict__ s1,
                                                           const float* __restrict__ t1, int swish,
                                                           int flip) {
-  constexpr int VEC = Tr<T>::VEC, CH = SA_C32 / VEC, RPP = 256 / CH, TILE = 256, PITCH = 36;
-  __shared__ __attribute__((aligned(16))) float xs[(TILE + SA_K15 - 1) * PITCH];
-  __shared__ __attribute__((aligned(16))) float ws[SA_K15][SA_C32];
-  const int tid = threadIdx.x, b = blockIdx.y, l0 = blockIdx.x * TILE;
+  constexpr int VEC = Tr<T>::VEC, CH = SA_C32 / VEC, RPP = 256 / CH, TILE = 128, PITCH = 36;
+  constexpr int NPOS = TILE + SA_K15 - 1, NBLK = (NPOS + 15) / 16, TP = 17;
+  constexpr int NIT = (NBLK * 16 + RPP - 1) / RPP;
+  __shared__ __attribute__((aligned(16))) float xs[NBLK * 16 * PITCH];
+  __shared__ float tp[NBLK * 16 * TP];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, b = blockIdx.y, l0 = blockIdx.x * TILE;
   {
     const int c = tid % CH, r0 = tid / CH;
     float sc[VEC], sh[VEC];
@@ -139,43 +144,51 @@ __global__ __launch_bounds__(256) void sa_convCto1_kernel(const T* __restrict__ 
       sc[j] = s1 ? s1[(size_t)b * SA_C32 + c * VEC + j] : 1.0f;
       sh[j] = t1 ? t1[(size_t)b * SA_C32 + c * VEC + j] : 0.0f;
     }
-    for (int r = r0; r < TILE + SA_K15 - 1; r += RPP) {
-      const int g = l0 + r - 7;
-      float f[VEC];
+    uint4 raw[NIT];                                   // all row loads in flight before the first use
 #pragma unroll
-      for (int j = 0; j < VEC; ++j) f[j] = 0.0f;
-      if (g >= 0 && g < L) {
-        const uint4 u = *reinterpret_cast<const uint4*>(x + ((size_t)b * L + g) * SA_C32 + c * VEC);
-        Tr<T>::unpack(u, f);
+    for (int i = 0; i < NIT; ++i) {
+      const int r = r0 + i * RPP, g = l0 + r - 7;
+      raw[i] = make_uint4(0, 0, 0, 0);
+      if (r < NPOS && g >= 0 && g < L)
+        raw[i] = *reinterpret_cast<const uint4*>(x + ((size_t)b * L + g) * SA_C32 + c * VEC);
+    }
+#pragma unroll
+    for (int i = 0; i < NIT; ++i) {
+      const int r = r0 + i * RPP, g = l0 + r - 7;
+      if (r < NBLK * 16) {
+        float f[VEC];
+        Tr<T>::unpack(raw[i], f);
+        const bool valid = r < NPOS && g >= 0 && g < L;
 #pragma unroll
         for (int j = 0; j < VEC; ++j) {
           float v = fmaf(f[j], sc[j], sh[j]);
-          f[j] = swish ? sa_swish(v) : v;
+          v = swish ? sa_swish(v) : v;
+          xs[r * PITCH + c * VEC + j] = valid ? v : 0.0f;
         }
       }
+    }
+  }
+  // B operand: w[c = 4*ks + (lane>>4)][tap slot n = lane&15] (slot 15 is zero)
+  const int n = lane & 15, kq = lane >> 4;
+  float wb[8];
 #pragma unroll
-      for (int j = 0; j < VEC; ++j) xs[r * PITCH + c * VEC + j] = f[j];
-    }
-    for (int i = tid; i < SA_K15 * SA_C32; i += 256) {
-      const int k = i / SA_C32, cc = i % SA_C32;
-      ws[k][cc] = w[cc * SA_K15 + (flip ? SA_K15 - 1 - k : k)];
-    }
+  for (int ks = 0; ks < 8; ++ks)
+    wb[ks] = n < SA_K15 ? w[(ks * 4 + kq) * SA_K15 + (flip ? SA_K15 - 1 - n : n)] : 0.0f;
+  __syncthreads();
+  for (int blk = wave; blk < NBLK; blk += 4) {
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    const float* ap = xs + (blk * 16 + n) * PITCH + kq;        // A[m = position][k = channel]
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(ap[ks * 4], wb[ks], acc, 0, 0, 0);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) tp[(blk * 16 + 4 * kq + i) * TP + n] = acc[i];
   }
   __syncthreads();
   const int l = l0 + tid;
-  if (l < L) {
+  if (tid < TILE && l < L) {
     float acc = bias ? bias[0] : 0.0f;
 #pragma unroll
-    for (int k = 0; k < SA_K15; ++k) {
-      const float4* xr = reinterpret_cast<const float4*>(&xs[(tid + k) * PITCH]);
-      const float4* wr = reinterpret_cast<const float4*>(&ws[k][0]);
-#pragma unroll
-      for (int q = 0; q < SA_C32 / 4; ++q) {
-        const float4 xv = xr[q], wv = wr[q];
-        acc = fmaf(xv.x, wv.x, acc); acc = fmaf(xv.y, wv.y, acc);
-        acc = fmaf(xv.z, wv.z, acc); acc = fmaf(xv.w, wv.w, acc);
-      }
-    }
+    for (int k = 0; k < SA_K15; ++k) acc += tp[(tid + k) * TP + k];
     y[(size_t)b * L + l] = acc;
   }
 }
@@ -185,7 +198,7 @@ extern "C" int sa_convCto1(int dtype, const void* x, const float* w, const float
                            void* stream) {
   if (!x || !w || !y || B <= 0 || L <= 0) return -22;
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-  dim3 grid(sa_div_up(L, 256), B);
+  dim3 grid(sa_div_up(L, 128), B);             // TILE of sa_convCto1_kernel
   if (dtype == SA_BF16)
     hipLaunchKernelGGL(sa_convCto1_kernel<bf16_t>, grid, dim3(256), 0, st,
                        reinterpret_cast<const bf16_t*>(x), w, bias, y, L, s1, t1, swish, flip);
