@@ -162,9 +162,12 @@ int sa_fin_bias(const double* sums, int B, int C, float* db, void* stream);
 /* ---- classifier head + losses (sa_head.hip): TDNNSexClassifier.forward reshape + pooling
  * (models/ConvAutoEncoder.py:61-66), classify (:47-55), log_softmax (:68); losses at
  * speechbrain_convae_train.py:105-108; utils/cosine_similarity_loss.py:53-56 ---------- */
+/* two stages: part [B][nseg][128 channels][128 row residues][2] (nseg = sa_pool_nseg(B)), then
+ * sa_pool_gather rotates / sums it into sums [B][128 pooled columns][2] (fp64) */
 int sa_pool_fwd(int dtype, const void* r, const float* scale, const float* shift, float* part, int B,
-                int L, void* stream);                            /* part [B][ntiles][128][2] */
-int sa_pool_ntiles(int L);
+                int L, int nseg, void* stream);
+int sa_pool_nseg(int B);
+int sa_pool_gather(const float* part, int B, int nseg, int L, double* sums, void* stream);
 int sa_pool_fin(const double* sums, int B, int n, const float* noise, float eps, float* pooled,
                 float* mean, float* stdraw, void* stream);
 /* stats (optional, [B][ceil(L/256)][128][2]): partial (sum g, sum g*(r-bn_mean[c])*bn_rstd[c]) of

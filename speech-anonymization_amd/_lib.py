@@ -64,7 +64,7 @@ SYMBOLS = [
     "sa_conv1toC", "sa_conv1toC_ntiles", "sa_convCto1", "sa_wgrad1C", "sa_wgrad1C_nchunk",
     "sa_sum_slabs", "sa_ew_stats", "sa_ew_apply", "sa_ew_ntiles", "sa_act_stats",
     "sa_sum_partials", "sa_sum_rows_d", "sa_fin_in_fwd", "sa_fin_bn_fwd", "sa_fin_bn_eval", "sa_fin_norm_bwd", "sa_fin_bias",
-    "sa_pool_fwd", "sa_pool_ntiles", "sa_pool_fin", "sa_pool_bwd", "sa_dense", "sa_colsums",
+    "sa_pool_fwd", "sa_pool_nseg", "sa_pool_gather", "sa_pool_fin", "sa_pool_bwd", "sa_dense", "sa_colsums",
     "sa_bn2d_bwd", "sa_dense_wgrad", "sa_log_softmax", "sa_log_softmax_bwd",
     "sa_loss_workspace_bytes", "sa_recon_loss", "sa_cls_losses", "sa_cosine_loss",
     "sa_tdnn_fwd", "sa_time_pool", "sa_leaky_affine", "sa_cluster_mi", "sa_fbank", "sa_fbank_table_elems", "sa_fbank_ntiles", "sa_fbank_scratch_bytes", "sa_fbank_normalize",

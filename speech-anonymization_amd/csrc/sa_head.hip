@@ -12,71 +12,108 @@
 // major memory order, has flat index f = c*L + l; the reshape regroups it so that pooled
 // column j collects every f with f % 128 == j.  Here the tensor is channels-last [B][L][128]
 // (stored ReLU output r, BN affine applied on the fly), so element (l, c) belongs to column
-// j = (c*L + l) % 128.  One workgroup stages a 128-row tile in LDS and each thread sums one
-// column along the wrapped diagonals -> deterministic, coalesced, no atomics.
+// j = (c*L + l) % 128: for a fixed channel the column advances with l, so all rows with the same
+// l mod 128 fall into the same column.  Stage 1 (sa_pool_fwd) is therefore a plain strided
+// reduction with no transposition: thread (lm, 16-byte channel chunk) sums rows lm, lm+128, ...
+// of its segment in registers (coalesced: a workgroup reads 8 or 16 consecutive rows per step)
+// and leaves S[b][seg][c][lm] = (sum, sumsq); stage 2 (sa_pool_gather) rotates: column j
+// collects S[..][c][(j - c*L) mod 128] over c and the segments in a fixed order (fp64).
 // ---------------------------------------------------------------------------------
 template <typename T>
 __global__ __launch_bounds__(256) void sa_pool_fwd_kernel(const T* __restrict__ r,
                                                           const float* __restrict__ sc,
                                                           const float* __restrict__ sh,
                                                           float* __restrict__ part, int L,
-                                                          int ntiles) {
-  constexpr int C = 128, VEC = Tr<T>::VEC, CH = C / VEC, RPP = 256 / CH, PITCH = 129;
-  __shared__ float ts[128 * PITCH];
-  __shared__ float half[128][2];
-  const int tid = threadIdx.x, b = blockIdx.y, tile = blockIdx.x, l0 = tile * 128;
-  {
-    const int c = tid % CH, r0 = tid / CH;
-    float s[VEC], t[VEC];
+                                                          int nseg) {
+  constexpr int C = 128, VEC = Tr<T>::VEC, CH = C / VEC, RPB = 256 / CH, NG = 128 / RPB;
+  __shared__ float tile[RPB][C][2];
+  const int tid = threadIdx.x, b = blockIdx.y, grp = blockIdx.x % NG, seg = blockIdx.x / NG;
+  const int c = tid % CH, rl = tid / CH, lm = grp * RPB + rl;
+  float s[VEC], t[VEC], sum[VEC], sq[VEC];
 #pragma unroll
-    for (int j = 0; j < VEC; ++j) { s[j] = sc[c * VEC + j]; t[j] = sh[c * VEC + j]; }
-    for (int rr = r0; rr < 128; rr += RPP) {
-      const int l = l0 + rr;
-      float f[VEC];
+  for (int j = 0; j < VEC; ++j) { s[j] = sc[c * VEC + j]; t[j] = sh[c * VEC + j]; sum[j] = 0.f; sq[j] = 0.f; }
+  const int nk = (L + 127) / 128, per = (nk + nseg - 1) / nseg;
+  const int kbeg = seg * per, kend = (kbeg + per < nk) ? kbeg + per : nk;
+  const T* rb = r + (size_t)b * L * C + c * VEC;
+  for (int k0 = kbeg; k0 < kend; k0 += 4) {
+    uint4 raw[4];
 #pragma unroll
-      for (int j = 0; j < VEC; ++j) f[j] = 0.0f;
-      if (l < L) {
-        Tr<T>::unpack(*reinterpret_cast<const uint4*>(r + ((size_t)b * L + l) * C + c * VEC), f);
+    for (int i = 0; i < 4; ++i) {
+      const int l = lm + 128 * (k0 + i);
+      raw[i] = make_uint4(0, 0, 0, 0);
+      if (k0 + i < kend && l < L) raw[i] = *reinterpret_cast<const uint4*>(rb + (size_t)l * C);
+    }
 #pragma unroll
-        for (int j = 0; j < VEC; ++j) f[j] = fmaf(f[j], s[j], t[j]);
+    for (int i = 0; i < 4; ++i) {
+      const int l = lm + 128 * (k0 + i);
+      if (k0 + i < kend && l < L) {
+        float f[VEC];
+        Tr<T>::unpack(raw[i], f);
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) {
+          const float v = fmaf(f[j], s[j], t[j]);
+          sum[j] += v; sq[j] = fmaf(v, v, sq[j]);
+        }
       }
+    }
+  }
 #pragma unroll
-      for (int j = 0; j < VEC; ++j) ts[rr * PITCH + c * VEC + j] = f[j];
-    }
-  }
+  for (int j = 0; j < VEC; ++j) { tile[rl][c * VEC + j][0] = sum[j]; tile[rl][c * VEC + j][1] = sq[j]; }
   __syncthreads();
-  const int j = tid & 127, hsel = tid >> 7;
-  float s = 0.0f, q = 0.0f;
-  const int Lm = L % 128, l0m = l0 % 128;
-  for (int c = hsel * 64; c < hsel * 64 + 64; ++c) {
-    const int rr = ((j - (c * Lm) % 128 - l0m) % 128 + 256) % 128;
-    if (l0 + rr < L) {
-      const float v = ts[rr * PITCH + c];
-      s += v; q = fmaf(v, v, q);
-    }
-  }
-  if (hsel == 1) { half[j][0] = s; half[j][1] = q; }
-  __syncthreads();
-  if (hsel == 0) {
-    float* d = part + (((size_t)b * ntiles + tile) * 128 + j) * 2;
-    d[0] = s + half[j][0]; d[1] = q + half[j][1];
+  // [c][lm] layout: RPB consecutive lm (x 2 values) per channel are contiguous
+  float* dst = part + ((size_t)b * nseg + seg) * C * 128 * 2;
+  for (int e = tid; e < RPB * C * 2; e += 256) {
+    const int cc = e / (RPB * 2), w = e % (RPB * 2);
+    dst[((size_t)cc * 128 + grp * RPB) * 2 + w] = tile[w >> 1][cc][w & 1];
   }
 }
 
-extern "C" int sa_pool_ntiles(int L) { return sa_div_up(L, 128); }
+// sums[b][j] = sum_seg sum_c S[b][seg][c][(j - c*L) mod 128]   (fp64, fixed order)
+__global__ __launch_bounds__(256) void sa_pool_gather_kernel(const float* __restrict__ part, int nseg,
+                                                             int L, double* __restrict__ sums) {
+  __shared__ double half[128][2];
+  const int tid = threadIdx.x, b = blockIdx.x, j = tid & 127, h = tid >> 7, Lm = L % 128;
+  double s = 0.0, q = 0.0;
+  for (int seg = 0; seg < nseg; ++seg) {
+    const float2* p = reinterpret_cast<const float2*>(part) + ((size_t)b * nseg + seg) * 128 * 128;
+#pragma unroll 8
+    for (int c = h * 64; c < h * 64 + 64; ++c) {
+      const float2 v = p[(size_t)c * 128 + ((j - c * Lm) & 127)];
+      s += v.x; q += v.y;
+    }
+  }
+  if (h == 1) { half[j][0] = s; half[j][1] = q; }
+  __syncthreads();
+  if (h == 0) {
+    sums[((size_t)b * 128 + j) * 2 + 0] = s + half[j][0];
+    sums[((size_t)b * 128 + j) * 2 + 1] = q + half[j][1];
+  }
+}
+
+// segments per utterance: enough workgroups (16 or 8 row groups x B x nseg) to fill the chip
+extern "C" int sa_pool_nseg(int B) {
+  int n = 2048 / (B * 16);
+  return n < 1 ? 1 : (n > 8 ? 8 : n);
+}
 
 extern "C" int sa_pool_fwd(int dtype, const void* r, const float* scale, const float* shift,
-                           float* part, int B, int L, void* stream) {
-  if (!r || !scale || !shift || !part || B <= 0 || L <= 1) return -22;
+                           float* part, int B, int L, int nseg, void* stream) {
+  if (!r || !scale || !shift || !part || B <= 0 || L <= 1 || nseg < 1) return -22;
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-  const int nt = sa_div_up(L, 128);
-  dim3 grid(nt, B);
   if (dtype == SA_BF16)
-    hipLaunchKernelGGL(sa_pool_fwd_kernel<bf16_t>, grid, dim3(256), 0, st,
-                       reinterpret_cast<const bf16_t*>(r), scale, shift, part, L, nt);
+    hipLaunchKernelGGL(sa_pool_fwd_kernel<bf16_t>, dim3(8 * nseg, B), dim3(256), 0, st,
+                       reinterpret_cast<const bf16_t*>(r), scale, shift, part, L, nseg);
   else
-    hipLaunchKernelGGL(sa_pool_fwd_kernel<float>, grid, dim3(256), 0, st,
-                       reinterpret_cast<const float*>(r), scale, shift, part, L, nt);
+    hipLaunchKernelGGL(sa_pool_fwd_kernel<float>, dim3(16 * nseg, B), dim3(256), 0, st,
+                       reinterpret_cast<const float*>(r), scale, shift, part, L, nseg);
+  hipError_t e = hipGetLastError();
+  return e == hipSuccess ? 0 : -(int)e;
+}
+
+extern "C" int sa_pool_gather(const float* part, int B, int nseg, int L, double* sums, void* stream) {
+  if (!part || !sums || B <= 0 || nseg < 1) return -22;
+  hipLaunchKernelGGL(sa_pool_gather_kernel, dim3(B), dim3(256), 0,
+                     reinterpret_cast<hipStream_t>(stream), part, nseg, L, sums);
   hipError_t e = hipGetLastError();
   return e == hipSuccess ? 0 : -(int)e;
 }

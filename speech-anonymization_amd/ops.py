@@ -343,11 +343,12 @@ def act_stats(x, s1, t1, swish=True):
 def pool_fwd(r, scale, shift, noise=None, eps=1e-5):
     lib = L.load()
     B, Ln, _ = r.shape
-    nt = lib.sa_pool_ntiles(Ln)
-    part = torch.empty(B, nt, 128, 2, dtype=torch.float32, device=r.device)
-    L.check(lib.sa_pool_fwd(L.dt_code(r.dtype), _f(r), _f(scale), _f(shift), _f(part), B, Ln,
+    nseg = lib.sa_pool_nseg(B)
+    part = torch.empty(B, nseg, 128, 128, 2, dtype=torch.float32, device=r.device)
+    L.check(lib.sa_pool_fwd(L.dt_code(r.dtype), _f(r), _f(scale), _f(shift), _f(part), B, Ln, nseg,
                             L.stream()), "sa_pool_fwd")
-    sums = sum_partials(part, B)
+    sums = torch.empty(B, 128, 2, dtype=torch.float64, device=r.device)
+    L.check(lib.sa_pool_gather(_f(part), B, nseg, Ln, _f(sums), L.stream()), "sa_pool_gather")
     pooled = torch.empty(B, 256, dtype=torch.float32, device=r.device)
     mean = torch.empty(B, 128, dtype=torch.float32, device=r.device)
     sd = torch.empty(B, 128, dtype=torch.float32, device=r.device)
