@@ -263,17 +263,25 @@ __global__ __launch_bounds__(64) void sa_dense_kernel(const float* __restrict__ 
   f32x16 acc;
 #pragma unroll
   for (int i = 0; i < 16; ++i) acc[i] = 0.0f;
-  for (int k0 = 0; k0 < K; k0 += 2) {
-    const int k = k0 + kh;
-    float av = 0.0f, bv = 0.0f;
-    if (k < K) {
-      if (m < M) {
-        av = X[(size_t)m * lda + k];
-        if (ps) av = fmaf(av, ps[k], pt[k]);
+  // operands of 8 k-steps are requested together (a load -> MFMA loop would pay one L2 round
+  // trip per k-step: these GEMMs are latency-bound, M = batch size)
+  for (int k0 = 0; k0 < K; k0 += 16) {
+    float av[8], bv[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int k = k0 + 2 * u + kh;
+      av[u] = 0.0f; bv[u] = 0.0f;
+      if (k < K) {
+        if (m < M) {
+          av[u] = X[(size_t)m * lda + k];
+          if (ps) av[u] = fmaf(av[u], ps[k], pt[k]);
+        }
+        if (n < N) bv[u] = W[(size_t)k * sbk + (size_t)n * sbn];
       }
-      if (n < N) bv = W[(size_t)k * sbk + (size_t)n * sbn];
     }
-    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc, 0, 0, 0);
+#pragma unroll
+    for (int u = 0; u < 8; ++u)
+      if (k0 + 2 * u < K) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[u], bv[u], acc, 0, 0, 0);
   }
   if (n < N) {
     const float bb = bias ? bias[n] : 0.0f;
@@ -308,6 +316,7 @@ __global__ void sa_colsums_kernel(const float* __restrict__ X, const float* __re
   const int n = blockIdx.x * blockDim.x + threadIdx.x;
   if (n >= N) return;
   double s = 0.0, q = 0.0;
+#pragma unroll 8
   for (int m = 0; m < M; ++m) {
     const float x = X[(size_t)m * N + n];
     float h = H ? H[(size_t)m * N + n] : x;
@@ -361,6 +370,7 @@ __global__ void sa_dense_wgrad_kernel(const float* __restrict__ dY, const float*
   if (i >= N * K) return;
   const int n = i / K, k = i % K;
   float s = 0.0f;
+#pragma unroll 8
   for (int m = 0; m < M; ++m) {
     float x = X[(size_t)m * K + k];
     if (ps) x = fmaf(x, ps[k], pt[k]);
