@@ -32,7 +32,9 @@ class SaConvArgs(C.Structure):
                 ("rowmin", C.c_int), ("nrows", C.c_int), ("wlo_off", C.c_int), ("taps", SaTaps),
                 ("ep_mode", C.c_int), ("ep_xp_is_act", C.c_int), ("ep_bstride", C.c_int),
                 ("ep_x", vp), ("ep_g2", vp), ("ep_s1", vp), ("ep_t1", vp), ("ep_mean", vp), ("ep_rstd", vp),
-                ("a_out", vp)]
+                ("a_out", vp),
+                ("nb_x", vp), ("nb_c1", vp), ("nb_c2", vp), ("nb_c3", vp),
+                ("nb_bstride", C.c_int), ("nb_relu_mask", C.c_int), ("nb_colsum", vp)]
 
 
 class SaPackDesc(C.Structure):
@@ -46,7 +48,7 @@ class SaWgradArgs(C.Structure):
                 ("B", C.c_int), ("Lin", C.c_int), ("Ldy", C.c_int), ("Mrows", C.c_int),
                 ("chunk", C.c_int), ("nchunk", C.c_int),
                 ("ntaps", C.c_int), ("off", C.c_int * MAX_TAPS), ("ph", C.c_int * MAX_TAPS),
-                ("x_pre", C.c_int)]
+                ("x_pre", C.c_int), ("dy_pre", C.c_int)]
 
 
 class SaEwArgs(C.Structure):

@@ -101,6 +101,9 @@ class ConvAutoencoder(nn.Module):
         # forward convs also store their transformed input in bf16 for the weight gradient
         # (bf16x3 / bf16x1f models; +1/2 of the saved activations in memory, identical results)
         self.cache_wgrad_operand = cache_wgrad_operand
+        # with the cache: the norm-backward apply passes run in the prologue of the data-gradient
+        # convolutions (False: separate sa_ew_apply launches)
+        self.fuse_apply = True
         # option: weight-gradient GEMMs on a second stream beside the data-gradient convolutions of
         # the following layers.  Measured: the kernels do overlap, the step time does not change
         # (13.34 vs 13.35 ms at B=32), so it is off unless SA_OVERLAP_WGRAD=1.
@@ -180,6 +183,16 @@ def _packed(model, P):
 
 def _conv(x, w, *args, **kw):
     return ops.conv_gemm(x, w.img, *args, code=w.code, **kw)
+
+
+class _PendingApply:
+    """d z of a normalised layer together with the coefficients of d y = c1*dz + c2*y + c3 that the
+    next data-gradient convolution applies in its prologue (instead of a sa_ew_apply pass)."""
+    __slots__ = ("g", "y", "c", "per_c", "relu", "bias_key", "wgrads")
+
+    def __init__(self, g, y, c, per_c, relu, bias_key):
+        self.g, self.y, self.c, self.per_c, self.relu, self.bias_key = g, y, c, per_c, relu, bias_key
+        self.wgrads = []
 
 
 def _noise(model, B, device):
@@ -323,8 +336,31 @@ class _ConvAEFn(torch.autograd.Function):
             G[key] = newg(key).copy_(val.reshape(P[key].shape))
         W, A = S["W"], S["A"]
         pw = lambda k, kind: W[(k, kind)]
-        cg = _conv
         wg = functools.partial(ops.wgrad, code=ops.WGRAD_CODE[model.precision])
+        # with the bf16 operand caches in place the apply pass of every normalised layer whose
+        # gradient feeds a convolution moves into that convolution's prologue
+        fuse = bool(A) and model.fuse_apply and model.dgrad_kcode == L.BF16X3
+
+        def cg(gin, w, *args, **kw):
+            """data-gradient / forward-type launch; a _PendingApply input selects the
+            normalisation-backward prologue, which also emits the bf16 d y for the deferred weight
+            gradients and the column sums for the bias gradient."""
+            if not isinstance(gin, _PendingApply):
+                return _conv(gin, w, *args, **kw)
+            p = gin
+            dyc = torch.empty(p.g.shape, dtype=torch.bfloat16, device=p.g.device) if p.wgrads else None
+            want_cs = p.bias_key is not None and need[p.bias_key]
+            out = _conv(p.g, w, *args, a_out=dyc, nb=dict(x=p.y, c1=p.c[0], c2=p.c[1], c3=p.c[2],
+                                                           per_c=p.per_c, relu_mask=p.relu,
+                                                           want_colsum=want_cs), **kw)
+            if want_cs:
+                cs = out[-1]
+                out = out[:-1] if len(out) > 2 else out[0]
+                tot = ops.sum_partials(cs.view(cs.shape[0], cs.shape[1], cs.shape[2], 1), 1)
+                setg(p.bias_key, tot.view(-1))
+            for f in p.wgrads:
+                f(dyc)
+            return out
 
         def bias_from(stats, key, C):
             if need[key]:
@@ -343,6 +379,8 @@ class _ConvAEFn(torch.autograd.Function):
             c1, c2, c3 = ops.fin_norm_bwd(sums, sums, B * C, C, Ln, P[prefix + ".weight"], mean, rstd,
                                           dgamma=dg, dbeta=db)
             G[prefix + ".weight"], G[prefix + ".bias"] = dg, db
+            if fuse:
+                return _PendingApply(g, y, (c1, c2, c3), False, False, bias_key)
             st2 = ops.ew("apply", g, y, C, out=g, c1=c1, c2=c2, c3=c3)
             bias_from(st2, bias_key, C)
             return g                                             # now d y
@@ -366,6 +404,8 @@ class _ConvAEFn(torch.autograd.Function):
             c1, c2, c3 = ops.fin_norm_bwd(gsums, lsums, 128, 128, float(B * Ln * w), P[prefix + ".weight"],
                                           mean, rstd, sign=-1.0 if xp else 1.0, dgamma=dg, dbeta=db)
             G[prefix + ".weight"], G[prefix + ".bias"] = dg, db
+            if fuse and not xp:
+                return _PendingApply(g, r, (c1, c2, c3), True, True, bias_key)
             st2 = ops.ew("apply", g, r, 128, out=g, c1=c1, c2=c2, c3=c3, relu_mask=not xp, per_c=True,
                          want_stats=bias_key is not None, **kw)
             if bias_key:
@@ -391,16 +431,23 @@ class _ConvAEFn(torch.autograd.Function):
 
         def conv_wgrad(key, x, dy, cin, cout, sa, Mrows, K, dil, pad, **pro):
             if need[key]:
+                if isinstance(dy, _PendingApply):            # runs once the bf16 d y exists
+                    dy.wgrads.append(lambda dyc: conv_wgrad(key, x, dyc, cin, cout, sa, Mrows, K, dil, pad,
+                                                            dy_pre=True))
+                    return
                 if key in A:
-                    x, pro = A[key], dict(x_pre=True)
+                    x, pro = A[key], dict(x_pre=True, dy_pre=bool(pro.get("dy_pre")))
                 G[key] = on_side(lambda: wg(x, dy, cin, cout, sa, 1, [(k * dil - pad, 0) for k in range(K)],
                                             Mrows, newg(key), (K, cin * K, 1), **pro), x, dy)
 
-        def convT_wgrad(key, x, dy, cin, cout, Mrows):
+        def convT_wgrad(key, x, dy, cin, cout, Mrows, dy_pre=False):
             if need[key]:
+                if isinstance(dy, _PendingApply):
+                    dy.wgrads.append(lambda dyc: convT_wgrad(key, x, dyc, cin, cout, Mrows, dy_pre=True))
+                    return
                 pro = {}
                 if key in A:
-                    x, pro = A[key], dict(x_pre=True)
+                    x, pro = A[key], dict(x_pre=True, dy_pre=dy_pre)
                 G[key] = on_side(lambda: wg(x, dy, cin, cout, 1, 2, CONVT_WG_TAPS, Mrows, newg(key),
                                             (cout * K5, K5, 1), **pro), x, dy)
 

@@ -71,11 +71,11 @@ struct ConvCfg {
   }
 };
 
-template <typename T, int CIN, int COUT, int SA, int U, int TM>
+template <typename T, int CIN, int COUT, int SA, int U, int TM, bool PRO2>
 // (256, 2): with an explicit minimum of resident workgroups hipcc allocates one unified register
 // file (104 registers for 128->128) instead of parking weight fragments in AGPRs behind
 // v_accvgpr_write copies (32 extra instructions per 12 MFMAs in the main loop).
-__global__ __launch_bounds__(256, 2) void sa_conv_gemm_kernel(SaConvArgs a, int red_off) {
+__global__ __launch_bounds__(256, 2) void sa_conv_gemm_kernel(SaConvArgs a, int red_off, int col_off) {
   typedef ConvCfg<T, CIN, COUT, SA, U, TM> C;
   typedef Pol<T> P;
   typedef typename P::store_t S;
@@ -108,6 +108,10 @@ __global__ __launch_bounds__(256, 2) void sa_conv_gemm_kernel(SaConvArgs a, int 
     const bool has1 = a.s1 != nullptr, has2 = a.s2 != nullptr, sw = a.swish != 0;
     const S* xb = reinterpret_cast<const S*>(a.x) + (size_t)b * a.Lin * CIN + c * VEC;
     const int gbase = m0 * SA + a.rowmin;
+    // rows this tile owns (a_out, nb_colsum): its base rows; the last tile also the trailing halo
+    const int own_lo = m0 * SA;
+    int own_hi = tile == a.ntiles - 1 ? a.Lin : (m0 + C::BMB) * SA;
+    if (own_hi > a.Lin) own_hi = a.Lin;
     // All row loads of this thread are issued before the first one is consumed (a
     // load -> transform -> LDS-write loop would pay one HBM round trip per iteration).
     constexpr int NIT = ((C::BMB - 1) * SA + 1 + SA_MAX_HALO + C::RPPI - 1) / C::RPPI;
@@ -117,6 +121,25 @@ __global__ __launch_bounds__(256, 2) void sa_conv_gemm_kernel(SaConvArgs a, int 
       const int r = r0 + i * C::RPPI, g = gbase + r;
       raw[i] = make_uint4(0, 0, 0, 0);
       if (r < a.nrows && g >= 0 && g < a.Lin) raw[i] = *reinterpret_cast<const uint4*>(xb + (size_t)g * CIN);
+    }
+    // PRO2 (normalisation-backward prologue, SaConvArgs.nb_*): the rows are d z of the layer above;
+    // d y = c1*dz + c2*y + c3 [* (y > 0)] is formed here from the stored forward tensor y instead
+    // of in a separate sa_ew_apply pass over HBM
+    uint4 raw2[PRO2 ? NIT : 1];
+    float k1[VEC], k2[VEC], k3[VEC], csum[VEC];
+    if constexpr (PRO2) {
+      const S* x2 = reinterpret_cast<const S*>(a.nb_x) + (size_t)b * a.Lin * CIN + c * VEC;
+#pragma unroll
+      for (int i = 0; i < NIT; ++i) {
+        const int r = r0 + i * C::RPPI, g = gbase + r;
+        raw2[i] = make_uint4(0, 0, 0, 0);
+        if (r < a.nrows && g >= 0 && g < a.Lin) raw2[i] = *reinterpret_cast<const uint4*>(x2 + (size_t)g * CIN);
+      }
+#pragma unroll
+      for (int j = 0; j < VEC; ++j) {
+        const size_t q = (size_t)b * a.nb_bstride + c * VEC + j;
+        k1[j] = a.nb_c1[q]; k2[j] = a.nb_c2[q]; k3[j] = a.nb_c3[q]; csum[j] = 0.0f;
+      }
     }
 #ifdef SA_CONV_STAMPS
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -133,7 +156,7 @@ __global__ __launch_bounds__(256, 2) void sa_conv_gemm_kernel(SaConvArgs a, int 
         if (r < a.nrows) {
           float f[VEC];
           tr::unpack(raw[i], f);
-          if (g >= 0 && g < a.Lin) xform(f);
+          if (g >= 0 && g < a.Lin) xform(f, i, g);
           LT* dst = As + (size_t)r * C::APITCH + c * VEC;
           if constexpr (P::NPL == 2) {
             uint2 hi, lo;
@@ -151,15 +174,39 @@ __global__ __launch_bounds__(256, 2) void sa_conv_gemm_kernel(SaConvArgs a, int 
         }
       }
     };
-    if (!has1 && !has2 && !sw) {
-      stage_rows([](float*) {});
+    if constexpr (PRO2) {
+      stage_rows([&](float* f, int i, int g) {
+        float y[VEC];
+        tr::unpack(raw2[i], y);
+        const bool own = g >= own_lo && g < own_hi;
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) {
+          float v = fmaf(k1[j], f[j], fmaf(k2[j], y[j], k3[j]));
+          if (a.nb_relu_mask && !(y[j] > 0.0f)) v = 0.0f;
+          f[j] = v;
+          if (own) csum[j] += v;
+        }
+      });
+      if (a.nb_colsum) {
+        // column sums of d y over the owned rows (bias gradient of the layer below): lanes
+        // holding the same channel chunk are folded by shuffles, then one LDS slot per wave
+        float* colred = reinterpret_cast<float*>(smem + col_off);
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) {
+          float v = csum[j];
+          for (int off = C::CHI; off < 64; off <<= 1) v += __shfl_xor(v, off, 64);
+          if (lane < C::CHI) colred[wave * CIN + (lane % C::CHI) * VEC + j] = v;
+        }
+      }
+    } else if (!has1 && !has2 && !sw) {
+      stage_rows([](float*, int, int) {});
     } else if (has1 && sw && !has2) {
-      stage_rows([&](float* f) {
+      stage_rows([&](float* f, int, int) {
 #pragma unroll
         for (int j = 0; j < VEC; ++j) f[j] = sa_swish(fmaf(f[j], s1[j], t1[j]));
       });
     } else {
-      stage_rows([&](float* f) {
+      stage_rows([&](float* f, int, int) {
 #pragma unroll
         for (int j = 0; j < VEC; ++j) {
           float v = f[j];
@@ -176,6 +223,13 @@ __global__ __launch_bounds__(256, 2) void sa_conv_gemm_kernel(SaConvArgs a, int 
   // activation cache for sa_wgrad (x_pre): the bf16 (hi) plane of the rows this tile owns -- its
   // base rows, the last tile also the trailing halo -- goes out in 16-byte pieces; the stores
   // drain while the MFMA loop runs
+  if constexpr (PRO2) {
+    if (a.nb_colsum && tid < CIN) {
+      const float* colred = reinterpret_cast<const float*>(smem + col_off);
+      a.nb_colsum[((size_t)b * a.ntiles + tile) * CIN + tid] =
+          (colred[tid] + colred[CIN + tid]) + (colred[2 * CIN + tid] + colred[3 * CIN + tid]);
+    }
+  }
   if constexpr (sizeof(LT) == 2) {
     if (a.a_out) {
       constexpr int CH16 = CIN / 8;
@@ -375,7 +429,7 @@ __global__ __launch_bounds__(256, 2) void sa_conv_gemm_kernel(SaConvArgs a, int 
   }
 }
 
-template <typename T, int CIN, int COUT, int SA, int U, int TM>
+template <typename T, int CIN, int COUT, int SA, int U, int TM, bool PRO2 = false>
 static int launch_cfg(const SaConvArgs& a, hipStream_t st) {
   typedef ConvCfg<T, CIN, COUT, SA, U, TM> C;
   SaConvArgs args = a;
@@ -395,12 +449,16 @@ static int launch_cfg(const SaConvArgs& a, hipStream_t st) {
   args.nrows = (C::BMB - 1) * SA + (omax - omin) + 1;
   args.wlo_off = (wmax + 1) * C::KSTEPS * C::NT * 64;      // Frag units: hi image size
   // a_out: every input row must be staged by the tile that owns it
-  if (a.a_out && (sizeof(typename C::LT) != 2 || omin > 0 || (C::BMB - 1) * SA + omax < C::BMB * SA - 1 ||
-                  (args.ntiles - 1) * C::BMB * SA + omin + args.nrows < a.Lin))
+  if ((a.a_out || a.nb_colsum) &&
+      (omin > 0 || (C::BMB - 1) * SA + omax < C::BMB * SA - 1 ||
+       (args.ntiles - 1) * C::BMB * SA + omin + args.nrows < a.Lin))
     return -22;
-  const size_t lds = C::lds_bytes(args.nrows);
+  if (a.a_out && sizeof(typename C::LT) != 2) return -22;
+  if (PRO2 && (!a.nb_c1 || !a.nb_c2 || !a.nb_c3)) return -22;
+  const size_t tile_lds = C::lds_bytes(args.nrows);
+  const size_t lds = tile_lds + (PRO2 ? 4 * CIN * sizeof(float) : 0);
   if (lds > 160 * 1024) return -12;
-  auto kern = sa_conv_gemm_kernel<T, CIN, COUT, SA, U, TM>;
+  auto kern = sa_conv_gemm_kernel<T, CIN, COUT, SA, U, TM, PRO2>;
   static bool attr_set = false;
   if (!attr_set) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
@@ -409,7 +467,7 @@ static int launch_cfg(const SaConvArgs& a, hipStream_t st) {
     attr_set = true;
   }
   dim3 grid(args.ntiles, a.B);
-  hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, args, 0);
+  hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, args, 0, (int)tile_lds);
   hipError_t e = hipGetLastError();
   return e == hipSuccess ? 0 : -(int)e;
 }
@@ -441,22 +499,26 @@ extern "C" int sa_conv_gemm_ntiles(int cin, int cout, int u, int Lout) {
   return sa_div_up(sa_div_up(Lout, u), tm / u);
 }
 
-template <typename T, int CI, int CO, int S, int UU>
+template <typename T, int CI, int CO, int S, int UU, bool PRO2 = false>
 static int launch_tm(const SaConvArgs& a, hipStream_t st) {
   if constexpr (CI == 64 && CO == 32 && UU == 2) {
-    return launch_cfg<T, CI, CO, S, UU, 128>(a, st);
+    return launch_cfg<T, CI, CO, S, UU, 128, PRO2>(a, st);
   } else {
-    return tile_rows(CI, CO, UU) == 64 ? launch_cfg<T, CI, CO, S, UU, 64>(a, st)
-                                       : launch_cfg<T, CI, CO, S, UU, 128>(a, st);
+    return tile_rows(CI, CO, UU) == 64 ? launch_cfg<T, CI, CO, S, UU, 64, PRO2>(a, st)
+                                       : launch_cfg<T, CI, CO, S, UU, 128, PRO2>(a, st);
   }
 }
 
+// the normalisation-backward prologue (nb_x) is built for the bf16x3 policy only
 #define SA_CONV_CASE(CI, CO, S, UU)                                              \
-  if (cin == CI && cout == CO && sa == S && u == UU)                             \
+  if (cin == CI && cout == CO && sa == S && u == UU) {                           \
+    if (a->nb_x)                                                                 \
+      return dtype == SA_BF16X3 ? launch_tm<bf16x3_t, CI, CO, S, UU, true>(*a, st) : -22; \
     return dtype == SA_BF16 ? launch_tm<bf16_t, CI, CO, S, UU>(*a, st)           \
            : dtype == SA_BF16X3 ? launch_tm<bf16x3_t, CI, CO, S, UU>(*a, st)     \
            : dtype == SA_BF16X1F ? launch_tm<bf16x1f_t, CI, CO, S, UU>(*a, st)   \
-                                : launch_tm<float, CI, CO, S, UU>(*a, st);
+                                : launch_tm<float, CI, CO, S, UU>(*a, st);       \
+  }
 
 // C-ABI entry (see include/sa_hip.h).  Returns 0, or a negative hipError_t / errno.
 extern "C" int sa_conv_gemm(int dtype, int cin, int cout, int sa, int u, const SaConvArgs* a,

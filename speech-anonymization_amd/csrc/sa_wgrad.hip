@@ -159,11 +159,14 @@ __device__ static inline bf16x8 sa_tr_frag(const bf16_t* p, int rs) {
 // XPRE: the A rows come pre-transformed in bf16 (SaConvArgs.a_out of the forward launch): 8 elements
 // per 16-byte chunk, no prologue arithmetic, and the registers that frees hold a second in-flight
 // K-tile (loads are issued two tiles ahead).
-template <typename T, int CIN, int COUT, int SA, int U, bool XPRE = false>
+// YPRE: likewise the dY rows come as bf16 (SaConvArgs.a_out of the data-gradient launch whose
+// normalisation-backward prologue formed them).
+template <typename T, int CIN, int COUT, int SA, int U, bool XPRE = false, bool YPRE = false>
 struct WgCfg {
   typedef Pol<T> P;
   typedef typename P::lds_t LT;
   static constexpr int VECA = XPRE ? 8 : P::VEC;
+  static constexpr int VECB = YPRE ? 8 : P::VEC;
   static constexpr int NSETS = XPRE ? 2 : 1;
   static constexpr int MT = CIN / 32, NT = COUT / 32, NP = MT * NT;
   static constexpr int NW = NP >= 8 ? 8 : 4;                       // waves per workgroup
@@ -175,7 +178,7 @@ struct WgCfg {
   static constexpr int HALO = 8;                                   // max tap offset spread
   static constexpr int RA = KT * SA + HALO, RB = KT * U;           // staged rows
   static constexpr int PA = WgPitch<LT, CIN>::value, PB = WgPitch<LT, COUT>::value;
-  static constexpr int CHA = CIN / VECA, CHB = COUT / P::VEC;      // 16-byte chunks per row
+  static constexpr int CHA = CIN / VECA, CHB = COUT / VECB;        // 16-byte chunks per row
   static constexpr int NITA = (RA * CHA + NTHR - 1) / NTHR, NITB = (RB * CHB + NTHR - 1) / NTHR;
   static constexpr int AEL = P::NPL * RA * PA, BEL = P::NPL * RB * PB;     // lds_t elements
   static constexpr int BUFEL = (AEL + BEL + 7) & ~7;
@@ -183,18 +186,19 @@ struct WgCfg {
   static_assert(NW % NPG == 0 && NT % PPW == 0, "pair dealing");
   static_assert(NTHR % CHA == 0 && NTHR % CHB == 0, "chunk column must be fixed per thread");
   static_assert(!XPRE || (sizeof(LT) == 2 && P::NPL == 1), "pre-transformed A is a bf16 single-plane operand");
+  static_assert(!YPRE || XPRE, "bf16 dY comes with the bf16 A cache");
 };
 
-template <typename T, int CIN, int COUT, int SA, int U, bool XPRE>
-__global__ __launch_bounds__((WgCfg<T, CIN, COUT, SA, U, XPRE>::NTHR)) void sa_wgrad_kernel(SaWgradArgs a) {
-  typedef WgCfg<T, CIN, COUT, SA, U, XPRE> C;
+template <typename T, int CIN, int COUT, int SA, int U, bool XPRE, bool YPRE>
+__global__ __launch_bounds__((WgCfg<T, CIN, COUT, SA, U, XPRE, YPRE>::NTHR)) void sa_wgrad_kernel(SaWgradArgs a) {
+  typedef WgCfg<T, CIN, COUT, SA, U, XPRE, YPRE> C;
   typedef Pol<T> P;
   typedef typename P::store_t S;
   typedef typename P::lds_t LT;
   typedef typename P::Frag Frag;
   typedef Tr<S> tr;
   constexpr int VEC = P::VEC, KS = P::KS, NPL = P::NPL, KT = C::KT, PPW = C::PPW;
-  constexpr int PA = C::PA, PB = C::PB, NTHR = C::NTHR, VECA = C::VECA, NSETS = C::NSETS;
+  constexpr int PA = C::PA, PB = C::PB, NTHR = C::NTHR, VECA = C::VECA, VECB = C::VECB, NSETS = C::NSETS;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   LT* tiles = reinterpret_cast<LT*>(smem);
   float* coef = reinterpret_cast<float*>(smem + 2 * (size_t)C::BUFEL * sizeof(LT));   // s1 t1 s2 t2
@@ -228,7 +232,8 @@ __global__ __launch_bounds__((WgCfg<T, CIN, COUT, SA, U, XPRE>::NTHR)) void sa_w
   }
   typedef typename std::conditional<XPRE, bf16_t, S>::type SX;        // storage type of the A rows
   const SX* xb = reinterpret_cast<const SX*>(a.x) + (size_t)b * a.Lin * CIN;
-  const S* yb = reinterpret_cast<const S*>(a.dy) + (size_t)b * a.Ldy * COUT;
+  typedef typename std::conditional<YPRE, bf16_t, S>::type SY;        // storage type of the dY rows
+  const SY* yb = reinterpret_cast<const SY*>(a.dy) + (size_t)b * a.Ldy * COUT;
   const int dyend = mend * U < a.Ldy ? mend * U : a.Ldy;
   const int ca = tid % C::CHA, ra0 = tid / C::CHA, cb = tid % C::CHB, rb0 = tid / C::CHB;
   constexpr int RSA = NTHR / C::CHA, RSB = NTHR / C::CHB;           // row step per iteration slot
@@ -248,7 +253,7 @@ __global__ __launch_bounds__((WgCfg<T, CIN, COUT, SA, U, XPRE>::NTHR)) void sa_w
       const int r = rb0 + i * RSB, g = m0 * U + r;
       rs.b[i] = make_uint4(0, 0, 0, 0);
       if (m0 < mend && r < C::RB && g < dyend)
-        rs.b[i] = *reinterpret_cast<const uint4*>(yb + (size_t)g * COUT + cb * VEC);
+        rs.b[i] = *reinterpret_cast<const uint4*>(yb + (size_t)g * COUT + cb * VECB);
     }
   };
   auto put = [&](LT* base, int planes_stride, int pitch, int r, int c, const float* f) {
@@ -302,13 +307,21 @@ __global__ __launch_bounds__((WgCfg<T, CIN, COUT, SA, U, XPRE>::NTHR)) void sa_w
         }
       }
     }
+    if constexpr (YPRE) {
 #pragma unroll
-    for (int i = 0; i < C::NITB; ++i) {
-      const int r = rb0 + i * RSB;
-      if (r < C::RB) {
-        float f[VEC];
-        tr::unpack(rs.b[i], f);
-        put(Bt, C::RB * PB, PB, r, cb, f);
+      for (int i = 0; i < C::NITB; ++i) {
+        const int r = rb0 + i * RSB;
+        if (r < C::RB) *reinterpret_cast<uint4*>(Bt + (size_t)r * PB + cb * VECB) = rs.b[i];
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < C::NITB; ++i) {
+        const int r = rb0 + i * RSB;
+        if (r < C::RB) {
+          float f[VEC];
+          tr::unpack(rs.b[i], f);
+          put(Bt, C::RB * PB, PB, r, cb, f);
+        }
       }
     }
   };
@@ -417,9 +430,9 @@ extern "C" int sa_wgrad_kw(int cin, int cout) {
   return nw / (np / ppw);
 }
 
-template <typename T, int CIN, int COUT, int SA, int U, bool XPRE = false>
+template <typename T, int CIN, int COUT, int SA, int U, bool XPRE = false, bool YPRE = false>
 static int launch_wgrad(const SaWgradArgs& a, hipStream_t st) {
-  typedef WgCfg<T, CIN, COUT, SA, U, XPRE> C;
+  typedef WgCfg<T, CIN, COUT, SA, U, XPRE, YPRE> C;
   int omin = a.off[0], omax = a.off[0];
   for (int t = 1; t < a.ntaps; ++t) {
     omin = a.off[t] < omin ? a.off[t] : omin;
@@ -428,7 +441,7 @@ static int launch_wgrad(const SaWgradArgs& a, hipStream_t st) {
   if (omax - omin > C::HALO) return -22;
   for (int t = 0; t < a.ntaps; ++t) if (a.ph[t] < 0 || a.ph[t] >= U) return -22;
   if (C::LDS > 160 * 1024) return -12;
-  auto kern = sa_wgrad_kernel<T, CIN, COUT, SA, U, XPRE>;
+  auto kern = sa_wgrad_kernel<T, CIN, COUT, SA, U, XPRE, YPRE>;
   static bool attr_set = false;
   if (!attr_set) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
@@ -446,7 +459,8 @@ static int launch_wgrad(const SaWgradArgs& a, hipStream_t st) {
   if (cin == CI && cout == CO && sa == S && u == UU)                            \
     return dtype == SA_BF16 ? launch_wgrad<bf16_t, CI, CO, S, UU>(*a, st)       \
            : dtype == SA_BF16X3 ? launch_wgrad<bf16x3_t, CI, CO, S, UU>(*a, st) \
-           : dtype == SA_BF16X1F ? (a->x_pre ? launch_wgrad<bf16x1f_t, CI, CO, S, UU, true>(*a, st)  \
+           : dtype == SA_BF16X1F ? (a->dy_pre ? launch_wgrad<bf16x1f_t, CI, CO, S, UU, true, true>(*a, st) \
+                                    : a->x_pre ? launch_wgrad<bf16x1f_t, CI, CO, S, UU, true>(*a, st)     \
                                              : launch_wgrad<bf16x1f_t, CI, CO, S, UU>(*a, st)) \
                                 : launch_wgrad<float, CI, CO, S, UU>(*a, st);
 
@@ -455,7 +469,7 @@ extern "C" int sa_wgrad(int dtype, int cin, int cout, int sa, int u, const SaWgr
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   if (!a || !a->x || !a->dy || !a->slabs || a->ntaps < 1 || a->ntaps > SA_MAX_TAPS ||
       a->chunk <= 0 || a->chunk % 64 || a->nchunk * a->chunk < a->Mrows ||
-      (a->x_pre && dtype != SA_BF16X1F))
+      (a->x_pre && dtype != SA_BF16X1F) || (a->dy_pre && !a->x_pre))
     return -22;
   SA_WG_CASE(32, 64, 2, 1)
   SA_WG_CASE(64, 64, 1, 1)

@@ -136,11 +136,14 @@ class PackedWeights:
 
 
 def conv_gemm(x, wp, bias, cin, cout, sa, u, phases, Lout, s1=None, t1=None, s2=None, t2=None,
-              swish=False, relu=False, want_stats=False, out=None, code=None, ep=None, a_out=None):
+              swish=False, relu=False, want_stats=False, out=None, code=None, ep=None, a_out=None,
+              nb=None):
     """x [B, Lin, cin] -> y [B, Lout, cout] (+ per-tile partial stats [B, ntiles, cout, 2]).
     ep: fused backward epilogue dict(mode=1|2, x=, g2=, s1=, t1=, mean=, rstd=, xp_is_act=,
     per_c=) -- see SaConvArgs.ep_* in include/sa_hip.h.  a_out: optional bf16 [B, Lin, cin] tensor
-    that receives the transformed input rows (the A operand of wgrad(..., x_pre=True))."""
+    that receives the transformed input rows (the A operand of wgrad(..., x_pre=True)).
+    nb=dict(x=, c1=, c2=, c3=, per_c=, relu_mask=, want_colsum=): normalisation-backward prologue
+    (SaConvArgs.nb_*); with want_colsum the per-tile column sums [B, ntiles, cin] are returned last."""
     lib = L.load()
     B, Lin, _ = x.shape
     assert x.shape[2] == cin
@@ -156,6 +159,14 @@ def conv_gemm(x, wp, bias, cin, cout, sa, u, phases, Lout, s1=None, t1=None, s2=
     if a_out is not None:
         assert a_out.dtype == torch.bfloat16 and a_out.shape == x.shape
         a.a_out = _f(a_out)
+    colsum = None
+    if nb:
+        assert nb["x"].shape == x.shape and nb["x"].dtype == x.dtype
+        a.nb_x, a.nb_c1, a.nb_c2, a.nb_c3 = _f(nb["x"]), _f(nb["c1"]), _f(nb["c2"]), _f(nb["c3"])
+        a.nb_bstride, a.nb_relu_mask = (0 if nb.get("per_c") else cin), int(bool(nb.get("relu_mask")))
+        if nb.get("want_colsum"):
+            colsum = torch.empty(B, nt, cin, dtype=torch.float32, device=x.device)
+            a.nb_colsum = _f(colsum)
     if ep:
         a.ep_mode, a.ep_xp_is_act = int(ep["mode"]), int(bool(ep.get("xp_is_act")))
         a.ep_bstride = 0 if ep.get("per_c") else cout
@@ -172,19 +183,26 @@ def conv_gemm(x, wp, bias, cin, cout, sa, u, phases, Lout, s1=None, t1=None, s2=
         extra = (a_out.numel() * 2 if a_out is not None else 0)        # bf16 operand cache written
         if ep:
             extra += y.numel() * esz * (2 if ep.get("g2") is not None else 1)   # stored forward tensor (+ 2nd gradient) read
+        if nb:
+            extra += x.numel() * esz                                             # stored forward tensor of the layer above
         PROFILE.stop(e0, (x.numel() + y.numel()) * esz + ntap * cin * cout * esz + extra,
                      2 * B * (-(-Lout // u)) * ntap * cin * cout)
-    return (y, stats) if want_stats else y
+    out_t = (y, stats) if want_stats else (y,)
+    if nb and nb.get("want_colsum"):
+        out_t = out_t + (colsum,)
+    return out_t if len(out_t) > 1 else y
 
 
 WGRAD_TARGET_WGS = {True: 256, False: 512}
 
 
 def wgrad(x, dy, cin, cout, sa, u, taps, Mrows, dst, dst_strides, s1=None, t1=None, s2=None,
-          t2=None, swish=False, accumulate=False, target_wgs=None, code=None, x_pre=False):
+          t2=None, swish=False, accumulate=False, target_wgs=None, code=None, x_pre=False,
+          dy_pre=False):
     """taps: list of (row_offset, phase) per weight tap.  dst: fp32 parameter-gradient tensor in
     PyTorch layout; dst_strides = (s_ci, s_co, s_tap).  x_pre: x is the bf16 a_out tensor of the
-    forward conv_gemm (already transformed; s1..swish are ignored)."""
+    forward conv_gemm (already transformed; s1..swish are ignored); dy_pre: dy is the bf16 a_out of
+    the data-gradient conv_gemm that formed it in its normalisation-backward prologue."""
     lib = L.load()
     B, Lin, _ = x.shape
     Ldy = dy.shape[1]
@@ -206,8 +224,10 @@ def wgrad(x, dy, cin, cout, sa, u, taps, Mrows, dst, dst_strides, s1=None, t1=No
     a.B, a.Lin, a.Ldy, a.Mrows, a.chunk, a.nchunk, a.ntaps = B, Lin, Ldy, Mrows, chunk, nchunk, nt
     for i, (off, ph) in enumerate(taps):
         a.off[i], a.ph[i] = off, ph
-    a.x_pre = int(x_pre)
-    L.check(lib.sa_wgrad(L.dt_code(dy.dtype) if code is None else code, cin, cout, sa, u,
+    a.x_pre, a.dy_pre = int(x_pre), int(dy_pre)
+    if dy_pre:
+        assert x_pre and dy.dtype == torch.bfloat16
+    L.check(lib.sa_wgrad((L.BF16X1F if dy_pre else L.dt_code(dy.dtype)) if code is None else code, cin, cout, sa, u,
                          C.byref(a), L.stream()),
             f"sa_wgrad({cin},{cout},{sa},{u})")
     sk, sn, st = dst_strides

@@ -110,8 +110,10 @@ def test_instance_norm_epilogue_statistics_at_scale():
 def test_bench_size_step_is_deterministic_and_cache_is_transparent():
     """BASELINE config 2 (B = 32, T = 1008) has no oracle run; properties instead: (1) the same
     step twice gives the same BITS in every output and gradient (fixed-order slab reductions, no
-    atomics); (2) the bf16 weight-gradient operand cache changes nothing (cache_wgrad_operand=False
-    recomputes the operand in the wgrad kernels: same products, same order)."""
+    atomics); (2) the bf16 operand caches and the apply pass fused into the data-gradient
+    prologues change nothing but the summation order of the conv-bias gradients
+    (cache_wgrad_operand=False: separate sa_ew_apply launches, operands recomputed in the wgrad
+    kernels -- same products, same order everywhere else)."""
     from oracle.features import synthetic_feats
     B, T = 32, 1008
     feats = synthetic_feats(B, T, seed=5).cuda()
@@ -125,7 +127,14 @@ def test_bench_size_step_is_deterministic_and_cache_is_transparent():
         r, l, g = _step(m, feats, gender)
         runs.append((r.clone(), l.clone(), {k: v.clone() for k, v in g.items()}))
         m.load_state_dict(sd)
-    for r, l, g in runs[1:]:
+    bias_of_normed_conv = {"encoder.2.bias", "encoder.5.bias", "encoder.8.bias", "encoder.11.bias",
+                           "decoder.1.bias", "decoder.5.bias", "sex_classifier.tdnn.0.bias",
+                           "sex_classifier.tdnn.3.bias", "sex_classifier.tdnn.6.bias"}
+    for n, (r, l, g) in enumerate(runs[1:]):
         assert torch.equal(r, runs[0][0]) and torch.equal(l, runs[0][1])
         for k in g:
-            assert torch.equal(g[k], runs[0][2][k]), k
+            if n == 1 and k in bias_of_normed_conv:          # cache off: other reduction order
+                scale = max(float(runs[0][2][k].abs().max()), float(g[k.replace(".bias", ".weight")].abs().max()))
+                assert float((g[k] - runs[0][2][k]).abs().max()) <= 1e-4 * scale, k
+            else:
+                assert torch.equal(g[k], runs[0][2][k]), k
