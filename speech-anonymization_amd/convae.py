@@ -360,6 +360,7 @@ class _ConvAEFn(torch.autograd.Function):
                 setg(p.bias_key, tot.view(-1))
             for f in p.wgrads:
                 f(dyc)
+            p.wgrads = []
             return out
 
         def bias_from(stats, key, C):
@@ -429,27 +430,35 @@ class _ConvAEFn(torch.autograd.Function):
             if ws is not None:
                 torch.cuda.current_stream().wait_stream(ws)
 
-        def conv_wgrad(key, x, dy, cin, cout, sa, Mrows, K, dil, pad, **pro):
-            if need[key]:
-                if isinstance(dy, _PendingApply):            # runs once the bf16 d y exists
-                    dy.wgrads.append(lambda dyc: conv_wgrad(key, x, dyc, cin, cout, sa, Mrows, K, dil, pad,
-                                                            dy_pre=True))
-                    return
-                if key in A:
-                    x, pro = A[key], dict(x_pre=True, dy_pre=bool(pro.get("dy_pre")))
-                G[key] = on_side(lambda: wg(x, dy, cin, cout, sa, 1, [(k * dil - pad, 0) for k in range(K)],
-                                            Mrows, newg(key), (K, cin * K, 1), **pro), x, dy)
+        def run_conv_wgrad(key, x, dy, cin, cout, sa, Mrows, K, dil, pad, pro):
+            if key in A:
+                x, pro = A[key], dict(x_pre=True, dy_pre=bool(pro.get("dy_pre")))
+            G[key] = on_side(lambda: wg(x, dy, cin, cout, sa, 1, [(k * dil - pad, 0) for k in range(K)],
+                                        Mrows, newg(key), (K, cin * K, 1), **pro), x, dy)
 
-        def convT_wgrad(key, x, dy, cin, cout, Mrows, dy_pre=False):
-            if need[key]:
-                if isinstance(dy, _PendingApply):
-                    dy.wgrads.append(lambda dyc: convT_wgrad(key, x, dyc, cin, cout, Mrows, dy_pre=True))
-                    return
-                pro = {}
-                if key in A:
-                    x, pro = A[key], dict(x_pre=True, dy_pre=dy_pre)
-                G[key] = on_side(lambda: wg(x, dy, cin, cout, 1, 2, CONVT_WG_TAPS, Mrows, newg(key),
-                                            (cout * K5, K5, 1), **pro), x, dy)
+        def conv_wgrad(key, x, dy, cin, cout, sa, Mrows, K, dil, pad, **pro):
+            if not need[key]:
+                return
+            if isinstance(dy, _PendingApply):                # runs once the bf16 d y exists
+                dy.wgrads.append(lambda dyc: run_conv_wgrad(key, x, dyc, cin, cout, sa, Mrows, K, dil, pad,
+                                                            dict(dy_pre=True)))
+            else:
+                run_conv_wgrad(key, x, dy, cin, cout, sa, Mrows, K, dil, pad, pro)
+
+        def run_convT_wgrad(key, x, dy, cin, cout, Mrows, dy_pre):
+            pro = {}
+            if key in A:
+                x, pro = A[key], dict(x_pre=True, dy_pre=dy_pre)
+            G[key] = on_side(lambda: wg(x, dy, cin, cout, 1, 2, CONVT_WG_TAPS, Mrows, newg(key),
+                                        (cout * K5, K5, 1), **pro), x, dy)
+
+        def convT_wgrad(key, x, dy, cin, cout, Mrows):
+            if not need[key]:
+                return
+            if isinstance(dy, _PendingApply):
+                dy.wgrads.append(lambda dyc: run_convT_wgrad(key, x, dyc, cin, cout, Mrows, True))
+            else:
+                run_convT_wgrad(key, x, dy, cin, cout, Mrows, False)
 
         if d_recon is None:
             d_recon = torch.zeros(B, T, 80, device=dev)
@@ -553,4 +562,9 @@ class _ConvAEFn(torch.autograd.Function):
         buckets.join()
         ctx.S = None
         grads = tuple(G[k] if need[k] else None for k in names)
+        # autograd's AccumulateGrad adopts a gradient only when nothing else references it (it
+        # clones otherwise: 56 copies per step): drop this frame's references explicitly rather than
+        # rely on the frame being collected before the engine looks
+        G.clear()
+        buckets.views.clear()
         return (None, None, d_feats) + grads

@@ -130,6 +130,11 @@ def test_bench_size_step_is_deterministic_and_cache_is_transparent():
     bias_of_normed_conv = {"encoder.2.bias", "encoder.5.bias", "encoder.8.bias", "encoder.11.bias",
                            "decoder.1.bias", "decoder.5.bias", "sex_classifier.tdnn.0.bias",
                            "sex_classifier.tdnn.3.bias", "sex_classifier.tdnn.6.bias"}
+    # the kernels write into flat stage buckets and autograd adopts those views as .grad (a stray
+    # reference to them makes AccumulateGrad clone all 56 gradients every step)
+    enc = [(k, p) for k, p in m.named_parameters() if k.startswith("encoder")]
+    for (k1, p1), (k2, p2) in zip(enc, enc[1:]):
+        assert p2.grad.data_ptr() - p1.grad.data_ptr() == 4 * p1.numel(), (k1, k2)
     for n, (r, l, g) in enumerate(runs[1:]):
         assert torch.equal(r, runs[0][0]) and torch.equal(l, runs[0][1])
         for k in g:
