@@ -76,6 +76,9 @@ typedef struct SaConvArgs {
    * [B][ntiles][CIN]: per-tile column sums of d y (bias gradient of the layer below). */
   const void* nb_x; const float* nb_c1; const float* nb_c2; const float* nb_c3;
   int nb_bstride, nb_relu_mask; float* nb_colsum;
+  /* optional (ep_mode with ep_g2): ep_g2 is d(BN output) of a BatchNorm over the activation
+   * swish(z); the epilogue uses k1[c]*ep_g2 + k2[c]*swish(z) + k3[c] in its place */
+  const float* ep_g2k1; const float* ep_g2k2; const float* ep_g2k3;
 } SaConvArgs;
 
 int sa_conv_gemm(int dtype, int cin, int cout, int sa, int u, const SaConvArgs* a, void* stream);

@@ -34,7 +34,8 @@ class SaConvArgs(C.Structure):
                 ("ep_x", vp), ("ep_g2", vp), ("ep_s1", vp), ("ep_t1", vp), ("ep_mean", vp), ("ep_rstd", vp),
                 ("a_out", vp),
                 ("nb_x", vp), ("nb_c1", vp), ("nb_c2", vp), ("nb_c3", vp),
-                ("nb_bstride", C.c_int), ("nb_relu_mask", C.c_int), ("nb_colsum", vp)]
+                ("nb_bstride", C.c_int), ("nb_relu_mask", C.c_int), ("nb_colsum", vp),
+                ("ep_g2k1", vp), ("ep_g2k2", vp), ("ep_g2k3", vp)]
 
 
 class SaPackDesc(C.Structure):

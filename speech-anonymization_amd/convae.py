@@ -370,7 +370,10 @@ class _ConvAEFn(torch.autograd.Function):
         def in_ep(y, nrm, g2=None):
             """fused-epilogue description of an [InstanceNorm -> swish] backward (stats pass)."""
             mean, rstd, scale, shift = nrm
-            return dict(mode=1, x=y, g2=g2, s1=scale, t1=shift, mean=mean, rstd=rstd)
+            d = dict(mode=1, x=y, g2=g2, s1=scale, t1=shift, mean=mean, rstd=rstd)
+            if isinstance(g2, _PendingApply):                 # apply of the `norm` BatchNorm rides along
+                d.update(g2=g2.g, g2k=g2.c)
+            return d
 
         def in_finish(g, st, y, nrm, C, Ln, prefix, bias_key):
             """g = d z (already multiplied by swish'), st = partial (sum dz, sum dz*yhat)."""
@@ -405,8 +408,8 @@ class _ConvAEFn(torch.autograd.Function):
             c1, c2, c3 = ops.fin_norm_bwd(gsums, lsums, 128, 128, float(B * Ln * w), P[prefix + ".weight"],
                                           mean, rstd, sign=-1.0 if xp else 1.0, dgamma=dg, dbeta=db)
             G[prefix + ".weight"], G[prefix + ".bias"] = dg, db
-            if fuse and not xp:
-                return _PendingApply(g, r, (c1, c2, c3), True, True, bias_key)
+            if fuse:
+                return _PendingApply(g, r, (c1, c2, c3), True, not xp, bias_key)
             st2 = ops.ew("apply", g, r, 128, out=g, c1=c1, c2=c2, c3=c3, relu_mask=not xp, per_c=True,
                          want_stats=bias_key is not None, **kw)
             if bias_key:

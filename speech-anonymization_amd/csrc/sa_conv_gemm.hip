@@ -358,6 +358,16 @@ __global__ __launch_bounds__(256, 2) void sa_conv_gemm_kernel(SaConvArgs a, int 
       emu[j] = (a.ep_mode && a.ep_mean) ? a.ep_mean[(size_t)b * a.ep_bstride + c * OVEC + j] : 0.0f;
       ers[j] = (a.ep_mode && a.ep_rstd) ? a.ep_rstd[(size_t)b * a.ep_bstride + c * OVEC + j] : 1.0f;
     }
+    // ep_g2k*: the second gradient is itself a pending BatchNorm-backward apply over the activation
+    // (the classifier's input BatchNorm behind GradReverse): g2 <- k1*g2 + k2*swish(z) + k3
+    const bool g2k = a.ep_mode && a.ep_g2 && a.ep_g2k1;
+    float gk1[OVEC], gk2[OVEC], gk3[OVEC];
+#pragma unroll
+    for (int j = 0; j < OVEC; ++j) {
+      gk1[j] = g2k ? a.ep_g2k1[c * OVEC + j] : 1.0f;
+      gk2[j] = g2k ? a.ep_g2k2[c * OVEC + j] : 0.0f;
+      gk3[j] = g2k ? a.ep_g2k3[c * OVEC + j] : 0.0f;
+    }
     S* yb = reinterpret_cast<S*>(a.y) + (size_t)b * a.Lout * COUT + c * OVEC;
     const S* xe = a.ep_mode ? reinterpret_cast<const S*>(a.ep_x) + (size_t)b * a.Lout * COUT + c * OVEC : nullptr;
     const S* ge = (a.ep_mode && a.ep_g2) ? reinterpret_cast<const S*>(a.ep_g2) + (size_t)b * a.Lout * COUT + c * OVEC : nullptr;
@@ -380,6 +390,7 @@ __global__ __launch_bounds__(256, 2) void sa_conv_gemm_kernel(SaConvArgs a, int 
 #pragma unroll
           for (int j = 0; j < OVEC; ++j) {
             const float z = fmaf(x[j], es1[j], et1[j]);
+            if (g2k) g2[j] = fmaf(gk1[j], g2[j], fmaf(gk2[j], sa_swish(z), gk3[j]));
             float gg = g[j] + g2[j];
             if (a.ep_mode == 1) gg *= sa_swish_grad(z);
             const float xv = a.ep_xp_is_act ? sa_swish(z) : x[j];

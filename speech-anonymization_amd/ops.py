@@ -173,6 +173,8 @@ def conv_gemm(x, wp, bias, cin, cout, sa, u, phases, Lout, s1=None, t1=None, s2=
         a.ep_x, a.ep_g2 = _f(ep["x"]), _f(ep.get("g2"))
         a.ep_s1, a.ep_t1 = _f(ep.get("s1")), _f(ep.get("t1"))
         a.ep_mean, a.ep_rstd = _f(ep.get("mean")), _f(ep.get("rstd"))
+        if ep.get("g2k") is not None:
+            a.ep_g2k1, a.ep_g2k2, a.ep_g2k3 = (_f(t) for t in ep["g2k"])
     e0 = PROFILE.start(f"conv_gemm({cin},{cout},{sa},{u})") if PROFILE.key else None
     L.check(lib.sa_conv_gemm(L.dt_code(x.dtype) if code is None else code, cin, cout, sa, u,
                              C.byref(a), L.stream()),
