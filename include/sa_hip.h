@@ -82,6 +82,9 @@ typedef struct SaConvArgs {
 } SaConvArgs;
 
 int sa_conv_gemm(int dtype, int cin, int cout, int sa, int u, const SaConvArgs* a, void* stream);
+/* sizeof(SaConvArgs | SaWgradArgs | SaEwArgs | SaPackDesc | SaTaps) for which = 0..4: lets a binding
+ * verify its mirror of these records (the library reads every field) */
+int sa_abi_sizeof(int which);
 int sa_conv_gemm_ntiles(int cin, int cout, int u, int Lout);
 int sa_conv_gemm_set_tile_rows(int rows);   /* tuning knob: 0 (default policy), 64 or 128 */
 

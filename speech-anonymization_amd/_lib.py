@@ -63,7 +63,7 @@ class SaEwArgs(C.Structure):
 
 # every symbol include/sa_hip.h declares (checked by tests/test_abi.py on CPU)
 SYMBOLS = [
-    "sa_conv_gemm", "sa_conv_gemm_ntiles", "sa_conv_gemm_set_tile_rows", "sa_pack_weights", "sa_pack_weights_multi", "sa_wgrad", "sa_wgrad_kw", "sa_wgrad_reduce",
+    "sa_conv_gemm", "sa_abi_sizeof", "sa_conv_gemm_ntiles", "sa_conv_gemm_set_tile_rows", "sa_pack_weights", "sa_pack_weights_multi", "sa_wgrad", "sa_wgrad_kw", "sa_wgrad_reduce",
     "sa_conv1toC", "sa_conv1toC_ntiles", "sa_convCto1", "sa_wgrad1C", "sa_wgrad1C_nchunk",
     "sa_sum_slabs", "sa_ew_stats", "sa_ew_apply", "sa_ew_ntiles", "sa_act_stats",
     "sa_sum_partials", "sa_sum_rows_d", "sa_fin_in_fwd", "sa_fin_bn_fwd", "sa_fin_bn_eval", "sa_fin_norm_bwd", "sa_fin_bias",
@@ -91,6 +91,10 @@ def load():
         _lib = C.CDLL(LIB_PATH)
         for s in SYMBOLS:
             getattr(_lib, s).restype = C.c_int
+        for i, rec in enumerate((SaConvArgs, SaWgradArgs, SaEwArgs, SaPackDesc, SaTaps)):
+            if _lib.sa_abi_sizeof(i) != C.sizeof(rec):
+                raise SaHipError(f"{rec.__name__}: binding has {C.sizeof(rec)} bytes, {LIB_PATH} "
+                                 f"{_lib.sa_abi_sizeof(i)} -- rebuild the library (stale build?)")
     return _lib
 
 

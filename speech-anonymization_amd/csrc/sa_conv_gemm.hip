@@ -531,6 +531,18 @@ static int launch_tm(const SaConvArgs& a, hipStream_t st) {
                                 : launch_tm<float, CI, CO, S, UU>(*a, st);       \
   }
 
+// sizeof of the argument records, for bindings to check their mirror of include/sa_hip.h
+extern "C" int sa_abi_sizeof(int which) {
+  switch (which) {
+    case 0: return (int)sizeof(SaConvArgs);
+    case 1: return (int)sizeof(SaWgradArgs);
+    case 2: return (int)sizeof(SaEwArgs);
+    case 3: return (int)sizeof(SaPackDesc);
+    case 4: return (int)sizeof(SaTaps);
+    default: return -22;
+  }
+}
+
 // C-ABI entry (see include/sa_hip.h).  Returns 0, or a negative hipError_t / errno.
 extern "C" int sa_conv_gemm(int dtype, int cin, int cout, int sa, int u, const SaConvArgs* a,
                             void* stream) {
