@@ -79,6 +79,9 @@ typedef struct SaConvArgs {
   /* optional (ep_mode with ep_g2): ep_g2 is d(BN output) of a BatchNorm over the activation
    * swish(z); the epilogue uses k1[c]*ep_g2 + k2[c]*swish(z) + k3[c] in its place */
   const float* ep_g2k1; const float* ep_g2k2; const float* ep_g2k3;
+  /* optional, launches with s1/t1 + swish and no s2: per-tile (sum, sum of squares) of the
+   * transformed input rows P(x), [B][ntiles][CIN][2] */
+  float* pro_stats;
 } SaConvArgs;
 
 int sa_conv_gemm(int dtype, int cin, int cout, int sa, int u, const SaConvArgs* a, void* stream);

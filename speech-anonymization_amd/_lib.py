@@ -35,7 +35,7 @@ class SaConvArgs(C.Structure):
                 ("a_out", vp),
                 ("nb_x", vp), ("nb_c1", vp), ("nb_c2", vp), ("nb_c3", vp),
                 ("nb_bstride", C.c_int), ("nb_relu_mask", C.c_int), ("nb_colsum", vp),
-                ("ep_g2k1", vp), ("ep_g2k2", vp), ("ep_g2k3", vp)]
+                ("ep_g2k1", vp), ("ep_g2k2", vp), ("ep_g2k3", vp), ("pro_stats", vp)]
 
 
 class SaPackDesc(C.Structure):

@@ -263,8 +263,14 @@ class _ConvAEFn(torch.autograd.Function):
         y4, st = cg(y3, pw("encoder.11.weight", "conv_fwd"), "encoder.11.weight", P["encoder.11.bias"], 128, 128, 1, 1,
                                ops.taps_conv(K5, 1, 2), L4, s1=n3[2], t1=n3[3], swish=True, want_stats=True)
         n4 = inorm(st, L4, "encoder.12", 128)
+        # decoder.0 goes first: it stages the same transformed encoder output the classifier's input
+        # BatchNorm needs statistics of, and leaves them as a by-product of its prologue
+        y5 = cg(y4, pw("decoder.0.weight", "conv_fwd"), "decoder.0.weight", P["decoder.0.bias"], 128, 128, 1, 1,
+                ops.taps_conv(K5, 1, 2), L4, s1=n4[2], t1=n4[3], swish=True, want_pro_stats=train)
+        if train:
+            y5, a4_stats = y5
         # ---------------- sex classifier (GradReverse = identity forward) ----------------
-        sums = ops.sum_partials(ops.act_stats(y4, n4[2], n4[3], True), 1) if train else None
+        sums = ops.sum_partials(a4_stats, 1) if train else None
         bn_n = bnorm(sums, B * L4, cls.norm, "sex_classifier.norm", 128)
         La, Lb, Lc = L4 - 4, L4 - 8, L4 - 14
         r0, st = cg(y4, pw("sex_classifier.tdnn.0.weight", "conv_fwd"), "sex_classifier.tdnn.0.weight",
@@ -291,8 +297,6 @@ class _ConvAEFn(torch.autograd.Function):
                            2, 64, ps=f2[2], pt=f2[3])
         logp = ops.log_softmax(logits)
         # ---------------- decoder ----------------
-        y5 = cg(y4, pw("decoder.0.weight", "conv_fwd"), "decoder.0.weight", P["decoder.0.bias"], 128, 128, 1, 1,
-                           ops.taps_conv(K5, 1, 2), L4, s1=n4[2], t1=n4[3], swish=True)
         y6, st = cg(y5, pw("decoder.1.weight", "convT_fwd"), "decoder.1.weight", P["decoder.1.bias"], 128, 64, 1, 2,
                                ops.UP2, L2, want_stats=True)
         n6 = inorm(st, L2, "decoder.2", 64)

@@ -200,6 +200,32 @@ __global__ __launch_bounds__(256, 2) void sa_conv_gemm_kernel(SaConvArgs a, int 
       }
     } else if (!has1 && !has2 && !sw) {
       stage_rows([](float*, int, int) {});
+    } else if (has1 && sw && !has2 && a.pro_stats) {
+      // forward launch that also leaves (sum, sum of squares) of its transformed input rows, per
+      // tile over the owned rows: the statistics of the activation for a BatchNorm that reads
+      // the same tensor (the classifier's input BatchNorm; saves a pass over the encoder output)
+      float ps[VEC], pq[VEC];
+#pragma unroll
+      for (int j = 0; j < VEC; ++j) { ps[j] = 0.0f; pq[j] = 0.0f; }
+      stage_rows([&](float* f, int, int g) {
+        const bool own = g >= own_lo && g < own_hi;
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) {
+          const float v = sa_swish(fmaf(f[j], s1[j], t1[j]));
+          f[j] = v;
+          if (own) { ps[j] += v; pq[j] = fmaf(v, v, pq[j]); }
+        }
+      });
+      float* colred = reinterpret_cast<float*>(smem + col_off);
+#pragma unroll
+      for (int j = 0; j < VEC; ++j) {
+        float v = ps[j], w = pq[j];
+        for (int off = C::CHI; off < 64; off <<= 1) { v += __shfl_xor(v, off, 64); w += __shfl_xor(w, off, 64); }
+        if (lane < C::CHI) {
+          colred[(wave * CIN + (lane % C::CHI) * VEC + j) * 2 + 0] = v;
+          colred[(wave * CIN + (lane % C::CHI) * VEC + j) * 2 + 1] = w;
+        }
+      }
     } else if (has1 && sw && !has2) {
       stage_rows([&](float* f, int, int) {
 #pragma unroll
@@ -223,6 +249,14 @@ __global__ __launch_bounds__(256, 2) void sa_conv_gemm_kernel(SaConvArgs a, int 
   // activation cache for sa_wgrad (x_pre): the bf16 (hi) plane of the rows this tile owns -- its
   // base rows, the last tile also the trailing halo -- goes out in 16-byte pieces; the stores
   // drain while the MFMA loop runs
+  if (!PRO2 && a.pro_stats && tid < CIN) {
+    const float* colred = reinterpret_cast<const float*>(smem + col_off);
+    float* d = a.pro_stats + (((size_t)b * a.ntiles + tile) * CIN + tid) * 2;
+#pragma unroll
+    for (int q = 0; q < 2; ++q)
+      d[q] = (colred[tid * 2 + q] + colred[(CIN + tid) * 2 + q]) +
+             (colred[(2 * CIN + tid) * 2 + q] + colred[(3 * CIN + tid) * 2 + q]);
+  }
   if constexpr (PRO2) {
     if (a.nb_colsum && tid < CIN) {
       const float* colred = reinterpret_cast<const float*>(smem + col_off);
@@ -460,14 +494,15 @@ static int launch_cfg(const SaConvArgs& a, hipStream_t st) {
   args.nrows = (C::BMB - 1) * SA + (omax - omin) + 1;
   args.wlo_off = (wmax + 1) * C::KSTEPS * C::NT * 64;      // Frag units: hi image size
   // a_out: every input row must be staged by the tile that owns it
-  if ((a.a_out || a.nb_colsum) &&
+  if ((a.a_out || a.nb_colsum || a.pro_stats) &&
       (omin > 0 || (C::BMB - 1) * SA + omax < C::BMB * SA - 1 ||
        (args.ntiles - 1) * C::BMB * SA + omin + args.nrows < a.Lin))
     return -22;
   if (a.a_out && sizeof(typename C::LT) != 2) return -22;
   if (PRO2 && (!a.nb_c1 || !a.nb_c2 || !a.nb_c3)) return -22;
+  if (a.pro_stats && (PRO2 || !a.s1 || !a.swish || a.s2)) return -22;   // affine + x*sigmoid(x) launches only
   const size_t tile_lds = C::lds_bytes(args.nrows);
-  const size_t lds = tile_lds + (PRO2 ? 4 * CIN * sizeof(float) : 0);
+  const size_t lds = tile_lds + (PRO2 ? 4 * CIN * sizeof(float) : a.pro_stats ? 8 * CIN * sizeof(float) : 0);
   if (lds > 160 * 1024) return -12;
   auto kern = sa_conv_gemm_kernel<T, CIN, COUT, SA, U, TM, PRO2>;
   static bool attr_set = false;

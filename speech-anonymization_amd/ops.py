@@ -137,13 +137,14 @@ class PackedWeights:
 
 def conv_gemm(x, wp, bias, cin, cout, sa, u, phases, Lout, s1=None, t1=None, s2=None, t2=None,
               swish=False, relu=False, want_stats=False, out=None, code=None, ep=None, a_out=None,
-              nb=None):
+              nb=None, want_pro_stats=False):
     """x [B, Lin, cin] -> y [B, Lout, cout] (+ per-tile partial stats [B, ntiles, cout, 2]).
     ep: fused backward epilogue dict(mode=1|2, x=, g2=, s1=, t1=, mean=, rstd=, xp_is_act=,
     per_c=) -- see SaConvArgs.ep_* in include/sa_hip.h.  a_out: optional bf16 [B, Lin, cin] tensor
     that receives the transformed input rows (the A operand of wgrad(..., x_pre=True)).
     nb=dict(x=, c1=, c2=, c3=, per_c=, relu_mask=, want_colsum=): normalisation-backward prologue
-    (SaConvArgs.nb_*); with want_colsum the per-tile column sums [B, ntiles, cin] are returned last."""
+    (SaConvArgs.nb_*); with want_colsum the per-tile column sums [B, ntiles, cin] are returned last.
+    want_pro_stats: also return per-tile (sum, sumsq) of the transformed input rows [B, ntiles, cin, 2]."""
     lib = L.load()
     B, Lin, _ = x.shape
     assert x.shape[2] == cin
@@ -159,6 +160,10 @@ def conv_gemm(x, wp, bias, cin, cout, sa, u, phases, Lout, s1=None, t1=None, s2=
     if a_out is not None:
         assert a_out.dtype == torch.bfloat16 and a_out.shape == x.shape
         a.a_out = _f(a_out)
+    pro_stats = None
+    if want_pro_stats:
+        pro_stats = torch.empty(B, nt, cin, 2, dtype=torch.float32, device=x.device)
+        a.pro_stats = _f(pro_stats)
     colsum = None
     if nb:
         assert nb["x"].shape == x.shape and nb["x"].dtype == x.dtype
@@ -192,6 +197,8 @@ def conv_gemm(x, wp, bias, cin, cout, sa, u, phases, Lout, s1=None, t1=None, s2=
     out_t = (y, stats) if want_stats else (y,)
     if nb and nb.get("want_colsum"):
         out_t = out_t + (colsum,)
+    if want_pro_stats:
+        out_t = out_t + (pro_stats,)
     return out_t if len(out_t) > 1 else y
 
 
