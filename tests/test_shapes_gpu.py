@@ -143,3 +143,26 @@ def test_bench_size_step_is_deterministic_and_cache_is_transparent():
                 assert float((g[k] - runs[0][2][k]).abs().max()) <= 1e-4 * scale, k
             else:
                 assert torch.equal(g[k], runs[0][2][k]), k
+
+
+@pytest.mark.parametrize("precision,limit", [("f32", 1e-8), ("bf16x3", 1e-4)])
+def test_input_gradient_matches_oracle(precision, limit):
+    """d loss / d feats (the reference never needs it: features come out of a no_grad front-end;
+    the module still provides it like any nn.Module): flipped-tap sa_convCto1 at the end of the
+    backward chain vs autograd through the oracle."""
+    from oracle.convae import ConvAutoencoder as OAE
+    from oracle.features import synthetic_feats
+    B, T = 4, 72
+    feats = synthetic_feats(B, T, seed=9)
+    m = _model(precision)
+    om = OAE(); om.load_state_dict(m.state_dict()); om.train()
+    fo = feats.clone().requires_grad_(True)
+    o_recon, o_logp = om(fo)
+    w_r, w_l = torch.randn(B, T, 80, generator=torch.Generator().manual_seed(1)), torch.randn(B, 2, generator=torch.Generator().manual_seed(2))
+    ((o_recon * w_r).sum() + (o_logp * w_l).sum()).backward()
+    fh = feats.cuda().requires_grad_(True)
+    recon, logp = m(fh)
+    torch.autograd.backward([recon, logp], [w_r.cuda(), w_l.cuda()])
+    torch.cuda.synchronize()
+    assert fh.grad is not None and fh.grad.shape == feats.shape
+    assert rel_mse(fh.grad, fo.grad) < limit
