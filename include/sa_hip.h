@@ -217,8 +217,11 @@ int sa_cosine_loss(const float* x1, const float* x2, int B, int S, int D, float*
 /* x-vector gender classifier forward (models/external_gender_classifiers.py:71-115,144-183;
  * evaluator_inference.yaml:34-48): TDNN block = speechbrain Conv1d (reflect "same" padding) ->
  * LeakyReLU -> BatchNorm1d(eval); StatisticsPooling over time with relative lengths. */
-int sa_tdnn_fwd(const float* x, const float* w, const float* bias, const float* bn_s, const float* bn_t,
-                float* y, int B, int T, int Cin, int Cout, int K, int dil, float slope, void* stream);
+/* wp: sa_pack_weights(SA_BF16X3, ...) image of the Conv1d weight zero-padded to Npad output channels
+ * (Npad % 128 == 0; ntaps = K, K = Cin (% 16 == 0), N = Npad, sk = K, sn = Cin*K, st = 1) */
+int sa_tdnn_fwd(const float* x, const void* wp, const float* bias, const float* bn_s, const float* bn_t,
+                float* y, int B, int T, int Cin, int Cout, int Npad, int K, int dil, float slope,
+                void* stream);
 int sa_time_pool(const float* x, const float* lens, const float* noise, int B, int T, int C, float eps,
                  float* out, void* stream);
 int sa_leaky_affine(const float* x, const float* s, const float* t, float slope, int M, int C, float* y,

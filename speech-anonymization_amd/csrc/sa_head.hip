@@ -568,62 +568,116 @@ extern "C" int sa_cosine_loss(const float* x1, const float* x2, int B, int S, in
 // -> LeakyReLU -> BatchNorm1d(eval), the block of models/external_gender_classifiers.py:71-87
 // (Xvector, used through evaluator_inference.yaml:34-41).  Activations are [B][T][C] already.
 //   y[b][t][co] = bn_s[co] * leaky( bias[co] + sum_{k,ci} x[b][refl(t + k*dil - pad)][ci] * w[co][ci][k] ) + bn_t[co]
-// Exact-f32 MFMA, one wave per 32x32 output tile; this is an evaluation-only path (not in the
-// train step), written for correctness first.
+// Tiled GEMM on the bf16 MFMA with split (hi/lo) operands, like the conv kernels: one 4-wave
+// workgroup = 128 frames x 128 output channels of one utterance; the input channels go through
+// LDS in chunks of <= 64 (frames + reflect halo staged and split once per chunk, every tap is a
+// row offset into the staged tile), weights come as the fragment-major image of sa_pack_weights
+// (SA_BF16X3, N padded to a multiple of 128) straight from L2.  Evaluation-only path.
 // ---------------------------------------------------------------------------------
-__global__ __launch_bounds__(64) void sa_tdnn_fwd_kernel(const float* __restrict__ x,
-                                                         const float* __restrict__ w,
-                                                         const float* __restrict__ bias,
-                                                         const float* __restrict__ bn_s,
-                                                         const float* __restrict__ bn_t,
-                                                         float* __restrict__ y, int B, int T, int Cin,
-                                                         int Cout, int K, int dil, float slope) {
-  const int lane = threadIdx.x, n0 = blockIdx.x * 32, m0 = blockIdx.y * 32;
-  const int M = B * T;
-  const int m = m0 + (lane & 31), n = n0 + (lane & 31), kh = lane >> 5;
-  const int pad = dil * (K - 1) / 2;
-  const int b = m < M ? m / T : 0, t = m < M ? m % T : 0;
-  f32x16 acc;
+#define SA_TD_BM 128
+#define SA_TD_BN 128
+#define SA_TD_CK 64
+#define SA_TD_HALO 8                      // >= dil*(K-1) for the x-vector layers (k5 d1, k3 d2, k3 d3)
+__global__ __launch_bounds__(256, 2) void sa_tdnn_fwd_kernel(const float* __restrict__ x,
+                                                             const bf16x8* __restrict__ wp,
+                                                             const float* __restrict__ bias,
+                                                             const float* __restrict__ bn_s,
+                                                             const float* __restrict__ bn_t,
+                                                             float* __restrict__ y, int T, int Cin,
+                                                             int Cout, int Npad, int K, int dil,
+                                                             float slope) {
+  constexpr int PITCH = SA_TD_CK + 8, ROWS = SA_TD_BM + SA_TD_HALO, PLANE = ROWS * PITCH;
+  __shared__ __attribute__((aligned(16))) bf16_t As[2 * PLANE];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wm = wave >> 1, wn = wave & 1;
+  const int t0 = blockIdx.x * SA_TD_BM, n0 = blockIdx.y * SA_TD_BN, b = blockIdx.z;
+  const int pad = dil * (K - 1) / 2, nrows = SA_TD_BM + 2 * pad;
+  const int KSTEPS = Cin / 16, NT = Npad / 32;
+  const size_t lo_off = (size_t)K * KSTEPS * NT * 64;            // fragments per weight plane
+  f32x16 acc[2][2];
 #pragma unroll
-  for (int i = 0; i < 16; ++i) acc[i] = 0.0f;
-  for (int k = 0; k < K; ++k) {
-    int tt = t + k * dil - pad;
-    if (tt < 0) tt = -tt;                                   // reflect (no edge repeat)
-    if (tt >= T) tt = 2 * (T - 1) - tt;
-    const float* xr = x + ((size_t)b * T + tt) * Cin;
-    for (int c0 = 0; c0 < Cin; c0 += 2) {
-      const int ci = c0 + kh;
-      float av = 0.0f, bv = 0.0f;
-      if (ci < Cin) {
-        if (m < M) av = xr[ci];
-        if (n < Cout) bv = w[((size_t)n * Cin + ci) * K + k];
+  for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) acc[mt][nt][i] = 0.0f;
+  const float* xb = x + (size_t)b * T * Cin;
+  for (int c0 = 0; c0 < Cin; c0 += SA_TD_CK) {
+    const int ck = Cin - c0 < SA_TD_CK ? Cin - c0 : SA_TD_CK, chunks = ck / 4;
+    // ---- stage rows t0-pad .. t0+BM+pad (reflected at the utterance ends), split hi / lo ----
+    for (int e = tid; e < nrows * chunks; e += 256) {
+      const int r = e / chunks, c = e % chunks;
+      int tt = t0 + r - pad;
+      if (tt < 0) tt = -tt;                                     // reflect (no edge repeat)
+      if (tt >= T) tt = 2 * (T - 1) - tt;
+      float f[4] = {0.f, 0.f, 0.f, 0.f};
+      if (tt >= 0 && tt < T) {
+        const float4 v = *reinterpret_cast<const float4*>(xb + (size_t)tt * Cin + c0 + c * 4);
+        f[0] = v.x; f[1] = v.y; f[2] = v.z; f[3] = v.w;
       }
-      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc, 0, 0, 0);
+      uint2 hi, lo;
+      sa_split4(f, hi, lo);
+      *reinterpret_cast<uint2*>(As + r * PITCH + c * 4) = hi;
+      *reinterpret_cast<uint2*>(As + PLANE + r * PITCH + c * 4) = lo;
     }
-  }
-  if (n < Cout) {
-    const float bb = bias ? bias[n] : 0.0f, s = bn_s ? bn_s[n] : 1.0f, sh = bn_t ? bn_t[n] : 0.0f;
+    __syncthreads();
+    const int ksteps = ck / 16;
+    for (int k = 0; k < K; ++k) {
+      for (int ks = 0; ks < ksteps; ++ks) {
+        const bf16x8* wt = wp + (((size_t)k * KSTEPS + c0 / 16 + ks) * NT + n0 / 32 + wn * 2) * 64 + lane;
+        bf16x8 bh[2], bl[2], ah[2], al[2];
 #pragma unroll
-    for (int i = 0; i < 16; ++i) {
-      const int mr = m0 + sa_acc_row(i, lane);
-      if (mr < M) {
-        float v = acc[i] + bb;
-        v = v > 0.0f ? v : v * slope;
-        y[(size_t)mr * Cout + n] = fmaf(v, s, sh);
+        for (int nt = 0; nt < 2; ++nt) { bh[nt] = wt[nt * 64]; bl[nt] = wt[lo_off + nt * 64]; }
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt) {
+          const bf16_t* ap = As + (wm * 64 + mt * 32 + (lane & 31) + k * dil) * PITCH + ks * 16 + 8 * (lane >> 5);
+          ah[mt] = *reinterpret_cast<const bf16x8*>(ap);
+          al[mt] = *reinterpret_cast<const bf16x8*>(ap + PLANE);
+        }
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+          for (int nt = 0; nt < 2; ++nt) {
+            acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[mt], bh[nt], acc[mt][nt], 0, 0, 0);
+            acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[mt], bl[nt], acc[mt][nt], 0, 0, 0);
+            acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[mt], bh[nt], acc[mt][nt], 0, 0, 0);
+          }
       }
+    }
+    __syncthreads();
+  }
+  // ---- bias -> LeakyReLU -> BatchNorm(eval) affine -> store ----
+#pragma unroll
+  for (int nt = 0; nt < 2; ++nt) {
+    const int n = n0 + (wn * 2 + nt) * 32 + (lane & 31);
+    if (n < Cout) {
+      const float bb = bias ? bias[n] : 0.0f, sc = bn_s ? bn_s[n] : 1.0f, sh = bn_t ? bn_t[n] : 0.0f;
+#pragma unroll
+      for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+          const int t = t0 + wm * 64 + mt * 32 + sa_acc_row(i, lane);
+          if (t < T) {
+            float v = acc[mt][nt][i] + bb;
+            v = v > 0.0f ? v : v * slope;
+            y[((size_t)b * T + t) * Cout + n] = fmaf(v, sc, sh);
+          }
+        }
     }
   }
 }
 
-extern "C" int sa_tdnn_fwd(const float* x, const float* w, const float* bias, const float* bn_s,
-                           const float* bn_t, float* y, int B, int T, int Cin, int Cout, int K,
+// wp: sa_pack_weights(SA_BF16X3, w padded to Npad output channels, ntaps = K, K = Cin, N = Npad,
+// sk = K, sn = Cin*K, st = 1); Npad % 128 == 0, Cin % 16 == 0.
+extern "C" int sa_tdnn_fwd(const float* x, const void* wp, const float* bias, const float* bn_s,
+                           const float* bn_t, float* y, int B, int T, int Cin, int Cout, int Npad, int K,
                            int dil, float slope, void* stream) {
-  if (!x || !w || !y || B <= 0 || T <= 0 || Cin <= 0 || Cout <= 0 || K < 1 || !(K & 1) || dil < 1 ||
-      dil * (K - 1) / 2 >= T)
+  if (!x || !wp || !y || B <= 0 || T <= 0 || Cin <= 0 || Cout <= 0 || K < 1 || !(K & 1) || dil < 1 ||
+      dil * (K - 1) / 2 >= T || dil * (K - 1) > SA_TD_HALO || Cin % 16 || Npad % SA_TD_BN || Npad < Cout)
     return -22;
-  dim3 grid(sa_div_up(Cout, 32), sa_div_up(B * T, 32));
-  hipLaunchKernelGGL(sa_tdnn_fwd_kernel, grid, dim3(64), 0, reinterpret_cast<hipStream_t>(stream), x, w,
-                     bias, bn_s, bn_t, y, B, T, Cin, Cout, K, dil, slope);
+  dim3 grid(sa_div_up(T, SA_TD_BM), Npad / SA_TD_BN, B);
+  hipLaunchKernelGGL(sa_tdnn_fwd_kernel, grid, dim3(256), 0, reinterpret_cast<hipStream_t>(stream), x,
+                     reinterpret_cast<const bf16x8*>(wp), bias, bn_s, bn_t, y, T, Cin, Cout, Npad, K, dil,
+                     slope);
   hipError_t e = hipGetLastError();
   return e == hipSuccess ? 0 : -(int)e;
 }

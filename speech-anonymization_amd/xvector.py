@@ -43,14 +43,31 @@ class _Marker(nn.Module):
     pass
 
 
+def _packed(conv):
+    """split-bf16 operand image of the (frozen, eval-mode) Conv1d weight, output channels zero-padded
+    to a multiple of 128; rebuilt when the parameter changes."""
+    w = conv.conv.weight
+    key = (w.data_ptr(), w._version, str(w.device))
+    if getattr(conv, "_img_key", None) != key:
+        Cout, Cin, K = w.shape
+        npad = -(-Cout // 128) * 128
+        wpad = w.detach()
+        if npad != Cout:
+            wpad = torch.cat([wpad, torch.zeros(npad - Cout, Cin, K, dtype=w.dtype, device=w.device)])
+        conv._img = ops.pack_weights(wpad.contiguous().float(), "conv_fwd", torch.float32, L.BF16X3)
+        conv._img_key, conv._npad = key, npad
+    return conv._img, conv._npad
+
+
 def _tdnn(x, conv, bn, slope=0.01):
     lib = L.load()
     B, T, Cin = x.shape
     Cout = conv.conv.out_channels
     _, _, s, t = bn.affine()
+    img, npad = _packed(conv)
     y = torch.empty(B, T, Cout, dtype=torch.float32, device=x.device)
-    L.check(lib.sa_tdnn_fwd(L.ptr(x), L.ptr(conv.conv.weight), L.ptr(conv.conv.bias), L.ptr(s), L.ptr(t),
-                            L.ptr(y), B, T, Cin, Cout, conv.kernel_size, conv.dilation,
+    L.check(lib.sa_tdnn_fwd(L.ptr(x), L.ptr(img), L.ptr(conv.conv.bias), L.ptr(s), L.ptr(t),
+                            L.ptr(y), B, T, Cin, Cout, npad, conv.kernel_size, conv.dilation,
                             C.c_float(slope), L.stream()), "sa_tdnn_fwd")
     return y
 
