@@ -130,12 +130,24 @@ class ConvAutoencoder(nn.Module):
 
     # ---- SyncBatchNorm support: statistics sums are all-reduced across data-parallel ranks
     # (what speechbrain's Brain applies under DDP); identity on one process.
+    def _bn_syncs(self):
+        import torch.distributed as dist
+        return self.sync_bn and dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+
     def _bn_allreduce(self, sums):
         import torch.distributed as dist
-        if self.sync_bn and dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        if self._bn_syncs():
             dist.all_reduce(sums)
             return dist.get_world_size()
         return 1
+
+    def _bn_global(self, local_sums):
+        """(global sums, world): the all-reduced copy of the local sums, or the local sums
+        themselves on one process (no copy)."""
+        if not self._bn_syncs():
+            return local_sums, 1
+        g = local_sums.clone()
+        return g, self._bn_allreduce(g)
 
 
 class _W:
@@ -406,8 +418,7 @@ class _ConvAEFn(torch.autograd.Function):
             mean, rstd = bn[0], bn[1]
             kw = dict(s1=xp[0], t1=xp[1], xp_is_act=True) if xp else {}
             lsums = ops.sum_partials(st, 1)
-            gsums = lsums.clone()
-            w = model._bn_allreduce(gsums)
+            gsums, w = model._bn_global(lsums)
             dg, db = newg(prefix + ".weight"), newg(prefix + ".bias")
             c1, c2, c3 = ops.fin_norm_bwd(gsums, lsums, 128, 128, float(B * Ln * w), P[prefix + ".weight"],
                                           mean, rstd, sign=-1.0 if xp else 1.0, dgamma=dg, dbeta=db)
@@ -480,13 +491,13 @@ class _ConvAEFn(torch.autograd.Function):
         G[c + "6.weight"] = ops.dense_wgrad(dLG, H2, newg(c + "6.weight"), ps=f2[2], pt=f2[3])
         setg(c + "6.bias", ops.colsums(dLG)[:, 0])
         dN2 = ops.dense(dLG, P[c + "6.weight"], None, 64, 2, transpose_w=True)
-        l2 = ops.colsums(dN2, H2, f2[0], f2[1]); g2s = l2.clone(); w = model._bn_allreduce(g2s)
+        l2 = ops.colsums(dN2, H2, f2[0], f2[1]); g2s, w = model._bn_global(l2)
         setg(c + "5.weight", l2[:, 1]); setg(c + "5.bias", l2[:, 0])
         dH2 = ops.bn2d_bwd(dN2, H2, g2s, B * w, P[c + "5.weight"], f2[0], f2[1], True)
         G[c + "3.weight"] = ops.dense_wgrad(dH2, H1, newg(c + "3.weight"), ps=f1[2], pt=f1[3])
         setg(c + "3.bias", ops.colsums(dH2)[:, 0])
         dN1 = ops.dense(dH2, P[c + "3.weight"], None, 128, 64, transpose_w=True)
-        l1 = ops.colsums(dN1, H1, f1[0], f1[1]); g1s = l1.clone(); w = model._bn_allreduce(g1s)
+        l1 = ops.colsums(dN1, H1, f1[0], f1[1]); g1s, w = model._bn_global(l1)
         setg(c + "2.weight", l1[:, 1]); setg(c + "2.bias", l1[:, 0])
         dH1 = ops.bn2d_bwd(dN1, H1, g1s, B * w, P[c + "2.weight"], f1[0], f1[1], True)
         G[c + "0.weight"] = ops.dense_wgrad(dH1, S["pooled"], newg(c + "0.weight"))
