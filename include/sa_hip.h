@@ -167,16 +167,17 @@ int sa_sum_partials(const float* slabs, double* dst, int nbatch, int nslab, int 
 int sa_sum_rows_d(const double* src, double* dst, int R, int n, void* stream);
 int sa_fin_in_fwd(const double* sums, int B, int C, int n, const float* gamma, const float* beta,
                   float eps, float* mean, float* rstd, float* scale, float* shift, void* stream);
-int sa_fin_bn_fwd(const double* sums, int C, double count, const float* gamma, const float* beta,
+/* sums of the BatchNorm finalisers may be R partial rows ([R][groups][2], added in row order) */
+int sa_fin_bn_fwd(const double* sums, int R, int C, double count, const float* gamma, const float* beta,
                   float eps, float momentum, float* run_mean, float* run_var, float* mean,
                   float* rstd, float* scale, float* shift, void* stream);
 int sa_fin_bn_eval(int C, const float* gamma, const float* beta, float eps, const float* run_mean,
                    const float* run_var, float* mean, float* rstd, float* scale, float* shift,
                    void* stream);
-int sa_fin_norm_bwd(const double* sums, const double* lsums, int groups, int C, double n,
+int sa_fin_norm_bwd(const double* sums, const double* lsums, int R, int groups, int C, double n,
                     const float* gamma, const float* mean, const float* rstd, float sign, float* c1,
                     float* c2, float* c3, float* dgamma, float* dbeta, void* stream);
-int sa_fin_bias(const double* sums, int B, int C, float* db, void* stream);
+int sa_fin_bias(const double* sums, int B, int C, int ncomp, float* db, void* stream);  /* sums [B][C][ncomp] */
 
 /* ---- classifier head + losses (sa_head.hip): TDNNSexClassifier.forward reshape + pooling
  * (models/ConvAutoEncoder.py:61-66), classify (:47-55), log_softmax (:68); losses at

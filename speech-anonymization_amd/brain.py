@@ -120,7 +120,16 @@ class Brain:
 
     def init_optimizers(self):
         if self.opt_class is not None and self.optimizer is None:
-            self.optimizer = self.opt_class(self.modules.parameters())
+            params = list(self.modules.parameters())
+            base = getattr(self.opt_class, "func", self.opt_class)
+            given = getattr(self.opt_class, "keywords", None) or {}
+            if base is torch.optim.Adam and "fused" not in given and params and all(p.is_cuda for p in params):
+                try:        # PyTorch's single-launch Adam: same update, ~8 fewer launches per step
+                    self.optimizer = self.opt_class(params, fused=True)
+                    return
+                except (TypeError, RuntimeError):
+                    pass
+            self.optimizer = self.opt_class(params)
 
     def check_gradients(self, loss):
         """speechbrain semantics: count non-finite losses (raise after `nonfinite_patience`),

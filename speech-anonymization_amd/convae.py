@@ -141,6 +141,10 @@ class ConvAutoencoder(nn.Module):
             return dist.get_world_size()
         return 1
 
+    def _bn_rows(self):
+        """per-utterance partial rows may go straight to the finalisers when nothing is all-reduced"""
+        return not self._bn_syncs()
+
     def _bn_global(self, local_sums):
         """(global sums, world): the all-reduced copy of the local sums, or the local sums
         themselves on one process (no copy)."""
@@ -257,9 +261,10 @@ class _ConvAEFn(torch.autograd.Function):
             w = model._bn_allreduce(sums)
             out = ops.fin_bn_fwd(sums, C, count * w, P[prefix + ".weight"], P[prefix + ".bias"],
                                  mod.running_mean, mod.running_var)
-            mod.num_batches_tracked += 1
+            tracked.append(mod.num_batches_tracked)
             return out
 
+        tracked = []                                            # BatchNorm step counters, bumped together
         enc, dec, cls = model.encoder, model.decoder, model.sex_classifier
         # ---------------- encoder ----------------
         y0 = ops.conv1toC(x0, P["encoder.0.weight"], P["encoder.0.bias"], dt)
@@ -282,22 +287,22 @@ class _ConvAEFn(torch.autograd.Function):
         if train:
             y5, a4_stats = y5
         # ---------------- sex classifier (GradReverse = identity forward) ----------------
-        sums = ops.sum_partials(a4_stats, 1) if train else None
+        sums = ops.sum_partials(a4_stats, 1, rows=model._bn_rows()) if train else None
         bn_n = bnorm(sums, B * L4, cls.norm, "sex_classifier.norm", 128)
         La, Lb, Lc = L4 - 4, L4 - 8, L4 - 14
         r0, st = cg(y4, pw("sex_classifier.tdnn.0.weight", "conv_fwd"), "sex_classifier.tdnn.0.weight",
                                P["sex_classifier.tdnn.0.bias"], 128, 128, 1, 1, ops.taps_conv(5, 1, 0), La,
                                s1=n4[2], t1=n4[3], swish=True, s2=bn_n[2], t2=bn_n[3], relu=True,
                                want_stats=True)
-        bn0 = bnorm(ops.sum_partials(st, 1), B * La, cls.tdnn[2], "sex_classifier.tdnn.2", 128)
+        bn0 = bnorm(ops.sum_partials(st, 1, rows=model._bn_rows()), B * La, cls.tdnn[2], "sex_classifier.tdnn.2", 128)
         r1, st = cg(r0, pw("sex_classifier.tdnn.3.weight", "conv_fwd"), "sex_classifier.tdnn.3.weight",
                                P["sex_classifier.tdnn.3.bias"], 128, 128, 1, 1, ops.taps_conv(3, 2, 0), Lb,
                                s2=bn0[2], t2=bn0[3], relu=True, want_stats=True)
-        bn1 = bnorm(ops.sum_partials(st, 1), B * Lb, cls.tdnn[5], "sex_classifier.tdnn.5", 128)
+        bn1 = bnorm(ops.sum_partials(st, 1, rows=model._bn_rows()), B * Lb, cls.tdnn[5], "sex_classifier.tdnn.5", 128)
         r2, st = cg(r1, pw("sex_classifier.tdnn.6.weight", "conv_fwd"), "sex_classifier.tdnn.6.weight",
                                P["sex_classifier.tdnn.6.bias"], 128, 128, 1, 1, ops.taps_conv(3, 3, 0), Lc,
                                s2=bn1[2], t2=bn1[3], relu=True, want_stats=True)
-        bn2 = bnorm(ops.sum_partials(st, 1), B * Lc, cls.tdnn[8], "sex_classifier.tdnn.8", 128)
+        bn2 = bnorm(ops.sum_partials(st, 1, rows=model._bn_rows()), B * Lc, cls.tdnn[8], "sex_classifier.tdnn.8", 128)
         pooled, pmean, psd = ops.pool_fwd(r2, bn2[2], bn2[3], noise=_noise(model, B, feats.device))
         H1 = ops.dense(pooled, P["sex_classifier.classify.0.weight"], P["sex_classifier.classify.0.bias"],
                        128, 256, relu=True)
@@ -319,6 +324,8 @@ class _ConvAEFn(torch.autograd.Function):
         n8 = inorm(st, Ltot, "decoder.6", 32)
         recon = ops.convCto1(y8, P["decoder.8.weight"], P["decoder.8.bias"], n8[2], n8[3], True)
 
+        if tracked:
+            torch._foreach_add_(tracked, 1)
         S.update(x0=x0, y=[y0, y1, y2, y3, y4, y5, y6, y7, y8], r=[r0, r1, r2],
                  n=[None, n1, n2, n3, n4, None, n6, None, n8], bn=[bn_n, bn0, bn1, bn2], f=[f1, f2],
                  pooled=pooled, pmean=pmean, psd=psd, H1=H1, H2=H2, logp=logp,
@@ -372,8 +379,9 @@ class _ConvAEFn(torch.autograd.Function):
             if want_cs:
                 cs = out[-1]
                 out = out[:-1] if len(out) > 2 else out[0]
-                tot = ops.sum_partials(cs.view(cs.shape[0], cs.shape[1], cs.shape[2], 1), 1)
-                setg(p.bias_key, tot.view(-1))
+                nb_, nt_, cc_ = cs.shape
+                G[p.bias_key] = ops.fin_bias(ops.sum_partials(cs.view(nb_, nt_, cc_, 1), nb_), nb_, cc_,
+                                             newg(p.bias_key), ncomp=1)
             for f in p.wgrads:
                 f(dyc)
             p.wgrads = []
@@ -417,7 +425,7 @@ class _ConvAEFn(torch.autograd.Function):
             encoder output, with GradReverse in front: sign -1, no ReLU mask)."""
             mean, rstd = bn[0], bn[1]
             kw = dict(s1=xp[0], t1=xp[1], xp_is_act=True) if xp else {}
-            lsums = ops.sum_partials(st, 1)
+            lsums = ops.sum_partials(st, 1, rows=model._bn_rows())
             gsums, w = model._bn_global(lsums)
             dg, db = newg(prefix + ".weight"), newg(prefix + ".bias")
             c1, c2, c3 = ops.fin_norm_bwd(gsums, lsums, 128, 128, float(B * Ln * w), P[prefix + ".weight"],

@@ -270,14 +270,19 @@ extern "C" int sa_fin_in_fwd(const double* sums, int B, int C, int n, const floa
 
 // BatchNorm (train mode) forward from (possibly all-reduced) sums over `count` elements per
 // channel; updates running_mean / running_var (unbiased) with `momentum` like nn.BatchNorm1d.
-__global__ void sa_fin_bn_fwd_kernel(const double* __restrict__ sums, int C, double count,
+// sums may come as R partial rows [R][C][2] (the per-utterance level of the slab reduction): they
+// are added here in row order, which saves a launch per BatchNorm
+__global__ void sa_fin_bn_fwd_kernel(const double* __restrict__ sums, int R, int C, double count,
                                      const float* __restrict__ gamma, const float* __restrict__ beta,
                                      float eps, float momentum, float* run_mean, float* run_var,
                                      float* mean, float* rstd, float* scale, float* shift) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= C) return;
-  const double m = (double)sums[2 * i] / count;
-  double var = (double)sums[2 * i + 1] / count - m * m;
+  double S = 0.0, Q = 0.0;
+#pragma unroll 8
+  for (int r = 0; r < R; ++r) { S += sums[2 * ((size_t)r * C + i)]; Q += sums[2 * ((size_t)r * C + i) + 1]; }
+  const double m = S / count;
+  double var = Q / count - m * m;
   if (var < 0.0) var = 0.0;
   const float r = (float)(1.0 / sqrt(var + (double)eps));
   const float sc = gamma[i] * r;
@@ -289,13 +294,13 @@ __global__ void sa_fin_bn_fwd_kernel(const double* __restrict__ sums, int C, dou
   }
 }
 
-extern "C" int sa_fin_bn_fwd(const double* sums, int C, double count, const float* gamma,
+extern "C" int sa_fin_bn_fwd(const double* sums, int R, int C, double count, const float* gamma,
                              const float* beta, float eps, float momentum, float* run_mean,
                              float* run_var, float* mean, float* rstd, float* scale, float* shift,
                              void* stream) {
-  if (!sums || !gamma || !beta || !mean || !rstd || !scale || !shift || count <= 0) return -22;
+  if (!sums || !gamma || !beta || !mean || !rstd || !scale || !shift || count <= 0 || R < 1) return -22;
   hipLaunchKernelGGL(sa_fin_bn_fwd_kernel, dim3(sa_div_up(C, 128)), dim3(128), 0,
-                     reinterpret_cast<hipStream_t>(stream), sums, C, count, gamma, beta, eps,
+                     reinterpret_cast<hipStream_t>(stream), sums, R, C, count, gamma, beta, eps,
                      momentum, run_mean, run_var, mean, rstd, scale, shift);
   hipError_t e = hipGetLastError();
   return e == hipSuccess ? 0 : -(int)e;
@@ -328,13 +333,15 @@ extern "C" int sa_fin_bn_eval(int C, const float* gamma, const float* beta, floa
 // sign = -1 folds the GradReverse layer in.  lsums (local sums, may equal sums) feed
 // d gamma = sum_b S2, d beta = sum_b S1 (written, not accumulated, when dgamma != null).
 __global__ void sa_fin_norm_bwd_kernel(const double* __restrict__ sums, const double* __restrict__ lsums,
-                                       int G, int C, double n, const float* __restrict__ gamma,
+                                       int R, int G, int C, double n, const float* __restrict__ gamma,
                                        const float* __restrict__ mean, const float* __restrict__ rstd,
                                        float sign, float* c1, float* c2, float* c3, float* dgamma,
                                        float* dbeta, int nb) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < G) {
-    const double S1 = sums[2 * i], S2 = sums[2 * i + 1];
+    double S1 = 0.0, S2 = 0.0;                          // R partial rows [R][G][2], added in row order
+#pragma unroll 8
+    for (int r = 0; r < R; ++r) { S1 += sums[2 * ((size_t)r * G + i)]; S2 += sums[2 * ((size_t)r * G + i) + 1]; }
     const double r = rstd[i], m = mean[i];
     const double k1 = (double)gamma[i % C] * r;
     c1[i] = sign * (float)k1;
@@ -343,38 +350,42 @@ __global__ void sa_fin_norm_bwd_kernel(const double* __restrict__ sums, const do
   }
   if (dgamma && i < C) {
     double a = 0.0, bsum = 0.0;
-    for (int b = 0; b < nb; ++b) { bsum += lsums[2 * ((size_t)b * C + i)]; a += lsums[2 * ((size_t)b * C + i) + 1]; }
+    for (int r = 0; r < R; ++r)
+      for (int b = 0; b < nb; ++b) {
+        bsum += lsums[2 * ((size_t)r * G + (size_t)b * C + i)];
+        a += lsums[2 * ((size_t)r * G + (size_t)b * C + i) + 1];
+      }
     dgamma[i] = (float)a; dbeta[i] = (float)bsum;
   }
 }
 
-extern "C" int sa_fin_norm_bwd(const double* sums, const double* lsums, int groups, int C, double n,
+extern "C" int sa_fin_norm_bwd(const double* sums, const double* lsums, int R, int groups, int C, double n,
                                const float* gamma, const float* mean, const float* rstd, float sign,
                                float* c1, float* c2, float* c3, float* dgamma, float* dbeta,
                                void* stream) {
-  if (!sums || !gamma || !mean || !rstd || !c1 || !c2 || !c3 || groups % C) return -22;
+  if (!sums || !gamma || !mean || !rstd || !c1 || !c2 || !c3 || groups % C || R < 1) return -22;
   const int tot = groups > C ? groups : C;
   hipLaunchKernelGGL(sa_fin_norm_bwd_kernel, dim3(sa_div_up(tot, 256)), dim3(256), 0,
-                     reinterpret_cast<hipStream_t>(stream), sums, lsums ? lsums : sums, groups, C,
+                     reinterpret_cast<hipStream_t>(stream), sums, lsums ? lsums : sums, R, groups, C,
                      n, gamma, mean, rstd, sign, c1, c2, c3, dgamma, dbeta, groups / C);
   hipError_t e = hipGetLastError();
   return e == hipSuccess ? 0 : -(int)e;
 }
 
-// bias gradient from per-(b,c) sums: db[c] = sum_b sums[b][c][0]
-__global__ void sa_fin_bias_kernel(const double* __restrict__ sums, int B, int C, float* db) {
+// bias gradient from per-(b,c) sums: db[c] = sum_b sums[b][c][0]   (sums [B][C][ncomp])
+__global__ void sa_fin_bias_kernel(const double* __restrict__ sums, int B, int C, int ncomp, float* db) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= C) return;
   double s = 0.0;
 #pragma unroll 8
-  for (int b = 0; b < B; ++b) s += sums[2 * ((size_t)b * C + i)];
+  for (int b = 0; b < B; ++b) s += sums[(size_t)ncomp * ((size_t)b * C + i)];
   db[i] = (float)s;
 }
 
-extern "C" int sa_fin_bias(const double* sums, int B, int C, float* db, void* stream) {
-  if (!sums || !db) return -22;
+extern "C" int sa_fin_bias(const double* sums, int B, int C, int ncomp, float* db, void* stream) {
+  if (!sums || !db || ncomp < 1) return -22;
   hipLaunchKernelGGL(sa_fin_bias_kernel, dim3(sa_div_up(C, 128)), dim3(128), 0,
-                     reinterpret_cast<hipStream_t>(stream), sums, B, C, db);
+                     reinterpret_cast<hipStream_t>(stream), sums, B, C, ncomp, db);
   hipError_t e = hipGetLastError();
   return e == hipSuccess ? 0 : -(int)e;
 }

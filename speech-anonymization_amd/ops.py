@@ -280,9 +280,11 @@ def wgrad1C(u, v, dst, flip=False, s1=None, t1=None, swish=False, accumulate=Fal
     return dst
 
 
-def sum_partials(part, nbatch, n=None):
+def sum_partials(part, nbatch, n=None, rows=False):
     """part [nbatch][nslab][n] (contiguous) -> [nbatch, n] fixed-order sums.  n defaults to the
-    product of the last two dims (the [.., C, 2] layout of the statistics slabs)."""
+    product of the last two dims (the [.., C, 2] layout of the statistics slabs).  rows=True (with
+    nbatch == 1): return the per-utterance partial rows [R, n] of the two-level reduction instead of
+    their sum -- the BatchNorm finalisers add them (fin_bn_fwd / fin_norm_bwd take R rows)."""
     lib = L.load()
     if n is None:
         n = part.shape[-2] * part.shape[-1]
@@ -293,6 +295,8 @@ def sum_partials(part, nbatch, n=None):
         R = part.shape[0]
         mid = torch.empty(R, n, dtype=torch.float64, device=part.device)
         L.check(lib.sa_sum_partials(_f(part), _f(mid), R, nslab // R, n, L.stream()), "sa_sum_partials")
+        if rows:
+            return mid
         out = torch.empty(1, n, dtype=torch.float64, device=part.device)
         L.check(lib.sa_sum_rows_d(_f(mid), _f(out), R, n, L.stream()), "sa_sum_rows_d")
         return out
@@ -312,7 +316,7 @@ def fin_in_fwd(sums, B, Cc, n, gamma, beta, eps=1e-5):
 def fin_bn_fwd(sums, Cc, count, gamma, beta, run_mean=None, run_var=None, eps=1e-5, momentum=0.1):
     lib = L.load()
     o = torch.empty(4, Cc, dtype=torch.float32, device=sums.device)
-    L.check(lib.sa_fin_bn_fwd(_f(sums), Cc, C.c_double(count), _f(gamma), _f(beta), C.c_float(eps),
+    L.check(lib.sa_fin_bn_fwd(_f(sums), sums.numel() // (2 * Cc), Cc, C.c_double(count), _f(gamma), _f(beta), C.c_float(eps),
                               C.c_float(momentum), _f(run_mean), _f(run_var), _f(o[0]), _f(o[1]),
                               _f(o[2]), _f(o[3]), L.stream()), "sa_fin_bn_fwd")
     return o[0], o[1], o[2], o[3]
@@ -329,14 +333,17 @@ def fin_bn_eval(Cc, gamma, beta, run_mean, run_var, eps=1e-5):
 def fin_norm_bwd(sums, lsums, groups, Cc, n, gamma, mean, rstd, sign=1.0, dgamma=None, dbeta=None):
     lib = L.load()
     o = torch.empty(3, groups, dtype=torch.float32, device=sums.device)
-    L.check(lib.sa_fin_norm_bwd(_f(sums), _f(lsums), groups, Cc, C.c_double(n), _f(gamma), _f(mean),
+    R = sums.numel() // (2 * groups)
+    assert lsums is None or lsums.numel() == sums.numel()
+    L.check(lib.sa_fin_norm_bwd(_f(sums), _f(lsums), R, groups, Cc, C.c_double(n), _f(gamma), _f(mean),
                                 _f(rstd), C.c_float(sign), _f(o[0]), _f(o[1]), _f(o[2]), _f(dgamma),
                                 _f(dbeta), L.stream()), "sa_fin_norm_bwd")
     return o[0], o[1], o[2]
 
 
-def fin_bias(sums, B, Cc, db):
-    L.check(L.load().sa_fin_bias(_f(sums), B, Cc, _f(db), L.stream()), "sa_fin_bias")
+def fin_bias(sums, B, Cc, db, ncomp=2):
+    """db[c] = sum_b sums[b][c][0]; sums [B, Cc, ncomp] fp64."""
+    L.check(L.load().sa_fin_bias(_f(sums), B, Cc, ncomp, _f(db), L.stream()), "sa_fin_bias")
     return db
 
 
