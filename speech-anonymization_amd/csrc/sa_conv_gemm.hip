@@ -307,8 +307,7 @@ __global__ __launch_bounds__(256, 2) void sa_conv_gemm_kernel(SaConvArgs a, int 
                       + (lane >> 5) * (C::KS / 2);
     auto load_group = [&](Frag (&dst)[P::NPL][KU], int g) {
       const int ti = g / GPT, kg = g % GPT;
-      const int ntw = (a.relu & 2) ? 0 : nt;     // (debug knob: all waves read the same weight slice)
-      const Frag* wt = wp + (((size_t)a.taps.widx[ph][ti] * C::KSTEPS + kg * KU) * C::NT + ntw) * 64 + lane;
+      const Frag* wt = wp + (((size_t)a.taps.widx[ph][ti] * C::KSTEPS + kg * KU) * C::NT + nt) * 64 + lane;
 #pragma unroll
       for (int ku = 0; ku < KU; ++ku) {
         dst[0][ku] = wt[(size_t)ku * C::NT * 64];
@@ -374,7 +373,7 @@ __global__ __launch_bounds__(256, 2) void sa_conv_gemm_kernel(SaConvArgs a, int 
       for (int i = 0; i < 16; ++i) {
         const int m = wm * C::MT * 32 + mt * 32 + sa_acc_row(i, lane);
         float val = acc[v][mt][i] + bv;
-        if (a.relu & 1) val = fmaxf(val, 0.0f);
+        if (a.relu) val = fmaxf(val, 0.0f);
         Os[(size_t)(m * U + ph) * C::OPITCH + col] = tr::from_f(val);
       }
     }
