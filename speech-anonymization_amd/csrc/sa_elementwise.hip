@@ -188,27 +188,29 @@ extern "C" int sa_act_stats(int dtype, int C, const void* x, const float* s1, co
 // ---------------------------------------------------------------------------------
 // batched slab sum: dst[bb][i] = sum_k slabs[bb][k][i]   (fixed order, double accumulate)
 // ---------------------------------------------------------------------------------
-// 256 threads = 32 outputs x 8 slab lanes (128-byte coalesced segments): lane q sums slabs q, q+8,
-// ... in order, then the 8 lane sums are added in lane order by one thread -> the same result on
+// 512 threads = 32 outputs x 16 slab lanes (128-byte coalesced segments): lane q sums slabs q,
+// q+16, ... in order (16 loads in flight per thread: the launch is latency-bound, one workgroup
+// per CU), then the 16 lane sums are added in lane order by one thread -> the same result on
 // every run.
-__global__ __launch_bounds__(256) void sa_sum_partials_kernel(const float* __restrict__ slabs,
-                                                              double* __restrict__ dst, int nslab,
-                                                              int n) {
-  __shared__ double part[8][33];
+#define SA_SP_LANES 16
+__global__ __launch_bounds__(32 * SA_SP_LANES) void sa_sum_partials_kernel(const float* __restrict__ slabs,
+                                                                           double* __restrict__ dst,
+                                                                           int nslab, int n) {
+  __shared__ double part[SA_SP_LANES][33];
   const int bb = blockIdx.y, o = threadIdx.x & 31, q = threadIdx.x >> 5;
   const int i = blockIdx.x * 32 + o;
   double s = 0.0;
   if (i < n) {
     const float* p = slabs + (size_t)bb * nslab * n + i;
-#pragma unroll 8
-    for (int k = q; k < nslab; k += 8) s += (double)p[(size_t)k * n];
+#pragma unroll 16
+    for (int k = q; k < nslab; k += SA_SP_LANES) s += (double)p[(size_t)k * n];
   }
   part[q][o] = s;
   __syncthreads();
   if (q == 0 && i < n) {
     double t = 0.0;
 #pragma unroll
-    for (int r = 0; r < 8; ++r) t += part[r][o];
+    for (int r = 0; r < SA_SP_LANES; ++r) t += part[r][o];
     dst[(size_t)bb * n + i] = t;
   }
 }
@@ -216,7 +218,7 @@ __global__ __launch_bounds__(256) void sa_sum_partials_kernel(const float* __res
 extern "C" int sa_sum_partials(const float* slabs, double* dst, int nbatch, int nslab, int n,
                                void* stream) {
   if (!slabs || !dst || nbatch <= 0 || nslab <= 0 || n <= 0) return -22;
-  hipLaunchKernelGGL(sa_sum_partials_kernel, dim3(sa_div_up(n, 32), nbatch), dim3(256), 0,
+  hipLaunchKernelGGL(sa_sum_partials_kernel, dim3(sa_div_up(n, 32), nbatch), dim3(32 * SA_SP_LANES), 0,
                      reinterpret_cast<hipStream_t>(stream), slabs, dst, nslab, n);
   hipError_t e = hipGetLastError();
   return e == hipSuccess ? 0 : -(int)e;
