@@ -68,7 +68,7 @@ typedef struct SaConvArgs {
   /* optional second output: the transformed input rows P(x) = s2*act(s1*x+t1)+t2, rounded to bf16,
    * [B][Lin][CIN] -- what sa_wgrad multiplies with when SaWgradArgs.x_pre is set */
   void* a_out;
-  /* normalisation-backward prologue (optional, SA_BF16X3 launches): x holds d z of the layer
+  /* normalisation-backward prologue (optional, SA_BF16X3 and SA_BF16 launches): x holds d z of the layer
    * above and nb_x its stored forward tensor y (same shape); the staged rows become
    * d y = nb_c1*dz + nb_c2*y + nb_c3 [zeroed where y <= 0 if nb_relu_mask], coefficients indexed
    * [b*nb_bstride + c] (nb_bstride = CIN or 0); s1..swish are ignored.  This is sa_ew_apply fused
@@ -120,7 +120,7 @@ typedef struct SaWgradArgs {
   int B, Lin, Ldy, Mrows, chunk, nchunk;
   int ntaps; int off[SA_MAX_TAPS]; int ph[SA_MAX_TAPS];
   int x_pre;   /* x is SaConvArgs.a_out of the forward launch (bf16, already transformed; s1..swish
-                * ignored).  SA_BF16X1F only. */
+                * ignored).  SA_BF16X1F and SA_BF16. */
   int dy_pre;  /* dy is SaConvArgs.a_out of the data-gradient launch that consumed it (bf16 d y);
                 * requires x_pre. */
 } SaWgradArgs;

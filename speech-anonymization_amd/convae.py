@@ -242,7 +242,7 @@ class _ConvAEFn(torch.autograd.Function):
         # activation cache: each conv also writes its transformed input rows in bf16, the operand
         # its weight gradient multiplies with (saves the recomputation and half of the bytes there)
         A = {}
-        cache_a = train and model.cache_wgrad_operand and ops.WGRAD_CODE[model.precision] == L.BF16X1F
+        cache_a = train and model.cache_wgrad_operand and ops.WGRAD_CODE[model.precision] in (L.BF16X1F, L.BF16)
 
         def cg(x, w, key, *args, **kw):
             if cache_a and key is not None and P[key].requires_grad:
@@ -362,7 +362,7 @@ class _ConvAEFn(torch.autograd.Function):
         wg = functools.partial(ops.wgrad, code=ops.WGRAD_CODE[model.precision])
         # with the bf16 operand caches in place the apply pass of every normalised layer whose
         # gradient feeds a convolution moves into that convolution's prologue
-        fuse = bool(A) and model.fuse_apply and model.dgrad_kcode == L.BF16X3
+        fuse = bool(A) and model.fuse_apply and model.dgrad_kcode in (L.BF16X3, L.BF16)
 
         def cg(gin, w, *args, **kw):
             """data-gradient / forward-type launch; a _PendingApply input selects the

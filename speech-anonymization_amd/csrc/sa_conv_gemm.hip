@@ -554,11 +554,12 @@ static int launch_tm(const SaConvArgs& a, hipStream_t st) {
   }
 }
 
-// the normalisation-backward prologue (nb_x) is built for the bf16x3 policy only
+// the normalisation-backward prologue (nb_x) is built for the bf16x3 and bf16 policies
 #define SA_CONV_CASE(CI, CO, S, UU)                                              \
   if (cin == CI && cout == CO && sa == S && u == UU) {                           \
     if (a->nb_x)                                                                 \
-      return dtype == SA_BF16X3 ? launch_tm<bf16x3_t, CI, CO, S, UU, true>(*a, st) : -22; \
+      return dtype == SA_BF16X3 ? launch_tm<bf16x3_t, CI, CO, S, UU, true>(*a, st) \
+             : dtype == SA_BF16 ? launch_tm<bf16_t, CI, CO, S, UU, true>(*a, st) : -22; \
     return dtype == SA_BF16 ? launch_tm<bf16_t, CI, CO, S, UU>(*a, st)           \
            : dtype == SA_BF16X3 ? launch_tm<bf16x3_t, CI, CO, S, UU>(*a, st)     \
            : dtype == SA_BF16X1F ? launch_tm<bf16x1f_t, CI, CO, S, UU>(*a, st)   \

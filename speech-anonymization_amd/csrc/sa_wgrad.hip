@@ -457,7 +457,9 @@ static int launch_wgrad(const SaWgradArgs& a, hipStream_t st) {
 
 #define SA_WG_CASE(CI, CO, S, UU)                                               \
   if (cin == CI && cout == CO && sa == S && u == UU)                            \
-    return dtype == SA_BF16 ? launch_wgrad<bf16_t, CI, CO, S, UU>(*a, st)       \
+    return dtype == SA_BF16 ? (a->dy_pre ? launch_wgrad<bf16_t, CI, CO, S, UU, true, true>(*a, st)    \
+                               : a->x_pre ? launch_wgrad<bf16_t, CI, CO, S, UU, true>(*a, st)       \
+                                          : launch_wgrad<bf16_t, CI, CO, S, UU>(*a, st))            \
            : dtype == SA_BF16X3 ? launch_wgrad<bf16x3_t, CI, CO, S, UU>(*a, st) \
            : dtype == SA_BF16X1F ? (a->dy_pre ? launch_wgrad<bf16x1f_t, CI, CO, S, UU, true, true>(*a, st) \
                                     : a->x_pre ? launch_wgrad<bf16x1f_t, CI, CO, S, UU, true>(*a, st)     \
@@ -469,7 +471,7 @@ extern "C" int sa_wgrad(int dtype, int cin, int cout, int sa, int u, const SaWgr
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   if (!a || !a->x || !a->dy || !a->slabs || a->ntaps < 1 || a->ntaps > SA_MAX_TAPS ||
       a->chunk <= 0 || a->chunk % 64 || a->nchunk * a->chunk < a->Mrows ||
-      (a->x_pre && dtype != SA_BF16X1F) || (a->dy_pre && !a->x_pre))
+      (a->x_pre && dtype != SA_BF16X1F && dtype != SA_BF16) || (a->dy_pre && !a->x_pre))
     return -22;
   SA_WG_CASE(32, 64, 2, 1)
   SA_WG_CASE(64, 64, 1, 1)

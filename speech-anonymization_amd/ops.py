@@ -216,7 +216,7 @@ def wgrad(x, dy, cin, cout, sa, u, taps, Mrows, dst, dst_strides, s1=None, t1=No
     B, Lin, _ = x.shape
     Ldy = dy.shape[1]
     if x_pre:
-        assert x.dtype == torch.bfloat16 and code == L.BF16X1F
+        assert x.dtype == torch.bfloat16 and code in (L.BF16X1F, L.BF16)
     nt = len(taps)
     kw = lib.sa_wgrad_kw(cin, cout)
     if target_wgs is None:
