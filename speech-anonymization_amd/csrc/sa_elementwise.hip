@@ -338,26 +338,42 @@ __global__ void sa_fin_norm_bwd_kernel(const double* __restrict__ sums, const do
                                        int R, int G, int C, double n, const float* __restrict__ gamma,
                                        const float* __restrict__ mean, const float* __restrict__ rstd,
                                        float sign, float* c1, float* c2, float* c3, float* dgamma,
-                                       float* dbeta, int nb) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < G) {
-    double S1 = 0.0, S2 = 0.0;                          // R partial rows [R][G][2], added in row order
+                                       float* dbeta, int nb, int coef_blocks) {
+  if ((int)blockIdx.x < coef_blocks) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < G) {
+      double S1 = 0.0, S2 = 0.0;                        // R partial rows [R][G][2], added in row order
 #pragma unroll 8
-    for (int r = 0; r < R; ++r) { S1 += sums[2 * ((size_t)r * G + i)]; S2 += sums[2 * ((size_t)r * G + i) + 1]; }
-    const double r = rstd[i], m = mean[i];
-    const double k1 = (double)gamma[i % C] * r;
-    c1[i] = sign * (float)k1;
-    c2[i] = sign * (float)(-k1 * r * S2 / n);
-    c3[i] = sign * (float)(k1 * (-S1 / n + m * r * S2 / n));
+      for (int r = 0; r < R; ++r) { S1 += sums[2 * ((size_t)r * G + i)]; S2 += sums[2 * ((size_t)r * G + i) + 1]; }
+      const double r = rstd[i], m = mean[i];
+      const double k1 = (double)gamma[i % C] * r;
+      c1[i] = sign * (float)k1;
+      c2[i] = sign * (float)(-k1 * r * S2 / n);
+      c3[i] = sign * (float)(k1 * (-S1 / n + m * r * S2 / n));
+    }
+    return;
   }
-  if (dgamma && i < C) {
-    double a = 0.0, bsum = 0.0;
-    for (int r = 0; r < R; ++r)
-      for (int b = 0; b < nb; ++b) {
-        bsum += lsums[2 * ((size_t)r * G + (size_t)b * C + i)];
-        a += lsums[2 * ((size_t)r * G + (size_t)b * C + i) + 1];
-      }
-    dgamma[i] = (float)a; dbeta[i] = (float)bsum;
+  // d gamma / d beta: 32 channels x 8 lanes per workgroup; lane q adds the (row, utterance) pairs
+  // q, q+8, ... in order, the 8 lane sums are added in lane order
+  __shared__ double part[8][32][2];
+  const int ch = ((int)blockIdx.x - coef_blocks) * 32 + (threadIdx.x & 31), q = threadIdx.x >> 5;
+  double a = 0.0, bsum = 0.0;
+  if (ch < C) {
+    const int tot = R * nb;
+#pragma unroll 4
+    for (int e = q; e < tot; e += 8) {
+      const int r = e / nb, b = e % nb;
+      const size_t at = 2 * ((size_t)r * G + (size_t)b * C + ch);
+      bsum += lsums[at]; a += lsums[at + 1];
+    }
+  }
+  part[q][threadIdx.x & 31][0] = bsum; part[q][threadIdx.x & 31][1] = a;
+  __syncthreads();
+  if (q == 0 && ch < C) {
+    double s0 = 0.0, s1 = 0.0;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) { s0 += part[k][threadIdx.x][0]; s1 += part[k][threadIdx.x][1]; }
+    dbeta[ch] = (float)s0; dgamma[ch] = (float)s1;
   }
 }
 
@@ -366,10 +382,12 @@ extern "C" int sa_fin_norm_bwd(const double* sums, const double* lsums, int R, i
                                float* c1, float* c2, float* c3, float* dgamma, float* dbeta,
                                void* stream) {
   if (!sums || !gamma || !mean || !rstd || !c1 || !c2 || !c3 || groups % C || R < 1) return -22;
-  const int tot = groups > C ? groups : C;
-  hipLaunchKernelGGL(sa_fin_norm_bwd_kernel, dim3(sa_div_up(tot, 256)), dim3(256), 0,
+  if ((dgamma == nullptr) != (dbeta == nullptr)) return -22;
+  const int coef_blocks = sa_div_up(groups, 256);
+  const int grid = coef_blocks + (dgamma ? sa_div_up(C, 32) : 0);
+  hipLaunchKernelGGL(sa_fin_norm_bwd_kernel, dim3(grid), dim3(256), 0,
                      reinterpret_cast<hipStream_t>(stream), sums, lsums ? lsums : sums, R, groups, C,
-                     n, gamma, mean, rstd, sign, c1, c2, c3, dgamma, dbeta, groups / C);
+                     n, gamma, mean, rstd, sign, c1, c2, c3, dgamma, dbeta, groups / C, coef_blocks);
   hipError_t e = hipGetLastError();
   return e == hipSuccess ? 0 : -(int)e;
 }

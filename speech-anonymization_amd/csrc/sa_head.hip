@@ -491,22 +491,31 @@ extern "C" int sa_recon_loss(const float* a, const float* b, long long n, int ki
 
 // NLLLoss(mean) and the confusion MSE against log(0.5) = -0.6931 (the reference's literal,
 // speechbrain_convae_train.py:107-108) on logp [B][2]; out = (nll, conf); grads per element.
-__global__ void sa_cls_losses_kernel(const float* __restrict__ logp, const long long* __restrict__ label,
-                                     int B, int NC, float* out, float* dnll, float* dconf) {
-  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+__global__ __launch_bounds__(64) void sa_cls_losses_kernel(const float* __restrict__ logp,
+                                                           const long long* __restrict__ label, int B, int NC,
+                                                           float* out, float* dnll, float* dconf) {
+  // lane t takes elements t, t+64, ...; the 64 lane sums are added in lane order
+  __shared__ double pn[64], pc[64];
+  const int t = threadIdx.x;
   double nll = 0.0, conf = 0.0;
-  for (int b = 0; b < B; ++b)
-    for (int c = 0; c < NC; ++c) {
-      const float lp = logp[b * NC + c];
-      const float d = lp - (-0.6931f);
-      conf += (double)d * d;
-      if (dconf) dconf[b * NC + c] = 2.0f * d / (float)(B * NC);
-      const bool hit = (long long)c == label[b];
-      if (hit) nll -= lp;
-      if (dnll) dnll[b * NC + c] = hit ? -1.0f / (float)B : 0.0f;
-    }
-  out[0] = (float)(nll / B);
-  out[1] = (float)(conf / (B * NC));
+  for (int e = t; e < B * NC; e += 64) {
+    const int b = e / NC, c = e % NC;
+    const float lp = logp[e];
+    const float d = lp - (-0.6931f);
+    conf += (double)d * d;
+    if (dconf) dconf[e] = 2.0f * d / (float)(B * NC);
+    const bool hit = (long long)c == label[b];
+    if (hit) nll -= lp;
+    if (dnll) dnll[e] = hit ? -1.0f / (float)B : 0.0f;
+  }
+  pn[t] = nll; pc[t] = conf;
+  __syncthreads();
+  if (t == 0) {
+    double a = 0.0, q = 0.0;
+    for (int i = 0; i < 64; ++i) { a += pn[i]; q += pc[i]; }
+    out[0] = (float)(a / B);
+    out[1] = (float)(q / (B * NC));
+  }
 }
 extern "C" int sa_cls_losses(const float* logp, const long long* label, int B, int NC, float* out,
                              float* dnll, float* dconf, void* stream) {
