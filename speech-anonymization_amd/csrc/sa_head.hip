@@ -252,20 +252,21 @@ extern "C" int sa_pool_bwd(int dtype, const void* r, const float* scale, const f
 //   P(v) = (v*ps[k] + pt[k]) (BatchNorm of the previous layer folded in), Bm(k,n) = W[k*sbk + n*sbn]
 // One wave per 32x32 output tile; rows >= M / cols >= N are masked.
 // ---------------------------------------------------------------------------------
-__global__ __launch_bounds__(64) void sa_dense_kernel(const float* __restrict__ X, int lda,
-                                                      const float* __restrict__ ps,
-                                                      const float* __restrict__ pt,
-                                                      const float* __restrict__ W, int sbk, int sbn,
-                                                      const float* __restrict__ bias, float* __restrict__ Y,
-                                                      int ldy, int M, int N, int K, int relu) {
-  const int lane = threadIdx.x, n0 = blockIdx.x * 32, m0 = blockIdx.y * 32;
+__global__ __launch_bounds__(256) void sa_dense_kernel(const float* __restrict__ X, int lda,
+                                                       const float* __restrict__ ps,
+                                                       const float* __restrict__ pt,
+                                                       const float* __restrict__ W, int sbk, int sbn,
+                                                       const float* __restrict__ bias, float* __restrict__ Y,
+                                                       int ldy, int M, int N, int K, int relu) {
+  // four waves share one 32x32 output tile: wave w takes the 16-deep k chunks w, w+4, ... (these
+  // GEMMs are latency-bound, M = batch size), the four partial tiles are added in wave order
+  __shared__ float part[4][16][64];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, n0 = blockIdx.x * 32, m0 = blockIdx.y * 32;
   const int m = m0 + (lane & 31), n = n0 + (lane & 31), kh = lane >> 5;
   f32x16 acc;
 #pragma unroll
   for (int i = 0; i < 16; ++i) acc[i] = 0.0f;
-  // operands of 8 k-steps are requested together (a load -> MFMA loop would pay one L2 round
-  // trip per k-step: these GEMMs are latency-bound, M = batch size)
-  for (int k0 = 0; k0 < K; k0 += 16) {
+  for (int k0 = wave * 16; k0 < K; k0 += 64) {
     float av[8], bv[8];
 #pragma unroll
     for (int u = 0; u < 8; ++u) {
@@ -283,13 +284,16 @@ __global__ __launch_bounds__(64) void sa_dense_kernel(const float* __restrict__ 
     for (int u = 0; u < 8; ++u)
       if (k0 + 2 * u < K) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[u], bv[u], acc, 0, 0, 0);
   }
-  if (n < N) {
+#pragma unroll
+  for (int i = 0; i < 16; ++i) part[wave][i][lane] = acc[i];
+  __syncthreads();
+  if (wave == 0 && n < N) {
     const float bb = bias ? bias[n] : 0.0f;
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
       const int mr = m0 + sa_acc_row(i, lane);
       if (mr < M) {
-        float v = acc[i] + bb;
+        float v = ((part[0][i][lane] + part[1][i][lane]) + part[2][i][lane]) + part[3][i][lane] + bb;
         if (relu) v = fmaxf(v, 0.0f);
         Y[(size_t)mr * ldy + n] = v;
       }
@@ -302,7 +306,7 @@ extern "C" int sa_dense(const float* X, int lda, const float* ps, const float* p
                         int relu, void* stream) {
   if (!X || !W || !Y || M <= 0 || N <= 0 || K <= 0) return -22;
   dim3 grid(sa_div_up(N, 32), sa_div_up(M, 32));
-  hipLaunchKernelGGL(sa_dense_kernel, grid, dim3(64), 0, reinterpret_cast<hipStream_t>(stream), X,
+  hipLaunchKernelGGL(sa_dense_kernel, grid, dim3(256), 0, reinterpret_cast<hipStream_t>(stream), X,
                      lda, ps, pt, W, sbk, sbn, bias, Y, ldy, M, N, K, relu);
   hipError_t e = hipGetLastError();
   return e == hipSuccess ? 0 : -(int)e;
