@@ -4,18 +4,25 @@
 // the reference reaches from models/ConvAutoEncoder.py:141-172 (encoder / decoder stacks)
 // and :33-43 (TDNN convs of the sex classifier).
 //
-// One workgroup (4 waves) produces 128 output rows x COUT channels of one utterance:
-//   prologue : the input rows it needs (128*SA/U + halo) are read ONCE from HBM with
-//              16-byte coalesced loads, transformed on the fly (InstanceNorm/BatchNorm
-//              affine + x*sigmoid(x), i.e. the producer's normalisation is applied here
-//              instead of in a separate pass) and staged in LDS;
+// One workgroup (4 waves) produces 64 or 128 output rows (per-shape policy, tile_rows()) x COUT
+// channels of one utterance:
+//   prologue : the input rows it needs (rows*SA/U + halo) are read ONCE from HBM with
+//              16-byte coalesced loads, transformed on the fly and staged in LDS (split into
+//              hi / lo bf16 planes in the bf16x3 mode).  The transform is either the producer's
+//              normalisation (InstanceNorm/BatchNorm affine + x*sigmoid(x): forward launches,
+//              optionally also emitting the bf16 operand cache `a_out` and its statistics
+//              `pro_stats`) or the normalisation BACKWARD apply d y = c1*dz + c2*y + c3 over two
+//              input tensors (data-gradient launches, `nb_*`; also emits bf16 d y and column
+//              sums) -- neither is a pass of its own over HBM;
 //   main loop: per tap and 16-deep (bf16) / 2-deep (f32) k-step, A fragments come from
 //              LDS (ds_read_b128, padded pitch => conflict-free), B fragments (weights,
 //              pre-packed fragment-major, L2-resident) straight from global memory;
 //              v_mfma_f32_32x32x16_bf16 / v_mfma_f32_32x32x2_f32, fp32 accumulate;
 //   epilogue : bias (+ReLU), transpose through LDS, 16-byte coalesced stores, and the
 //              per-(utterance, channel) sum / sum-of-squares of the stored values written
-//              as a per-tile partial slab (deterministic two-level reduction; no atomics).
+//              as a per-tile partial slab (deterministic two-level reduction; no atomics);
+//              data-gradient launches instead apply the activation backward and emit the
+//              normalisation-backward statistics of the layer above (`ep_*`).
 #include "sa_common.h"
 
 #define SA_MAX_HALO 16

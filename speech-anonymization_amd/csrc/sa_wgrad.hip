@@ -11,9 +11,11 @@
 // [row][channel] LDS tiles with the gfx950 hardware transpose read ds_read_b64_tr_b16
 // (cdna_hip_programming.md T10); a tap shift is then just a row offset.  The f32 path
 // (v_mfma_f32_32x32x2_f32, one k per lane) reads the same tiles with ds_read_b32.
-// Each workgroup owns one (utterance, row chunk) and writes fp32 partial slabs;
-// sa_wgrad_reduce sums the slabs in a fixed order (deterministic) straight into the
-// PyTorch weight layout.
+// Each workgroup owns one (utterance, row chunk) with the whole CIN x COUT block and all taps
+// and writes fp32 partial slabs; sa_wgrad_reduce sums the slabs in a fixed order
+// (deterministic) straight into the PyTorch weight layout.  In the training step both operands
+// arrive as bf16 caches written by the convolution launches (x_pre, dy_pre): the kernel is then
+// pure copy-to-LDS + MFMA and HBM-bound.
 #include "sa_common.h"
 #include <type_traits>
 
