@@ -4,6 +4,7 @@ Tensors are device memory handles only; all arithmetic happens in libsa_hip.so o
 current torch stream.  Activations are channels-last [B, L, C] (see include/sa_hip.h).
 """
 import ctypes as C
+import functools
 
 import torch
 
@@ -135,6 +136,13 @@ class PackedWeights:
                 "sa_pack_weights_multi")
 
 
+@functools.lru_cache(maxsize=None)
+def _conv_ntiles(cin, cout, u, Lout):
+    """statistics tiles per utterance of a launch (cached: the tile policy is fixed per process;
+    whoever calls sa_conv_gemm_set_tile_rows must do so before the first launch)"""
+    return L.load().sa_conv_gemm_ntiles(cin, cout, u, Lout)
+
+
 def conv_gemm(x, wp, bias, cin, cout, sa, u, phases, Lout, s1=None, t1=None, s2=None, t2=None,
               swish=False, relu=False, want_stats=False, out=None, code=None, ep=None, a_out=None,
               nb=None, want_pro_stats=False):
@@ -149,7 +157,7 @@ def conv_gemm(x, wp, bias, cin, cout, sa, u, phases, Lout, s1=None, t1=None, s2=
     B, Lin, _ = x.shape
     assert x.shape[2] == cin
     y = out if out is not None else torch.empty(B, Lout, cout, dtype=x.dtype, device=x.device)
-    nt = lib.sa_conv_gemm_ntiles(cin, cout, u, Lout)
+    nt = _conv_ntiles(cin, cout, u, Lout)
     stats = torch.empty(B, nt, cout, 2, dtype=torch.float32, device=x.device) if want_stats else None
     a = L.SaConvArgs()
     a.x, a.wp, a.bias, a.y = _f(x), _f(wp), _f(bias), _f(y)
