@@ -115,8 +115,11 @@ class ConvAutoencoder(nn.Module):
         self.sync_bn = sync_bn
 
     def forward(self, feats):
-        names, params = zip(*self.named_parameters())
-        return _ConvAEFn.apply(self, names, feats, *params)
+        c = getattr(self, "_np_cache", None)          # walking the module tree costs ~0.15 ms a call
+        if c is None or c[2] is not self.encoder[0].weight or c[3] is not self.decoder[6].bias:
+            names, params = zip(*self.named_parameters())
+            c = self._np_cache = (names, params, self.encoder[0].weight, self.decoder[6].bias)
+        return _ConvAEFn.apply(self, c[0], feats, *c[1])
 
     def _wgrad_stream(self, device):
         if getattr(self, "_wgs", None) is None and device.type == "cuda":
