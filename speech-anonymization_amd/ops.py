@@ -211,6 +211,9 @@ def conv_gemm(x, wp, bias, cin, cout, sa, u, phases, Lout, s1=None, t1=None, s2=
 
 
 WGRAD_TARGET_WGS = {True: 256, False: 512}
+if __import__("os").environ.get("SA_WG_TARGETS"):                    # tuning override "big,small"
+    _b, _s = __import__("os").environ["SA_WG_TARGETS"].split(",")
+    WGRAD_TARGET_WGS = {True: int(_b), False: int(_s)}
 
 
 def wgrad(x, dy, cin, cout, sa, u, taps, Mrows, dst, dst_strides, s1=None, t1=None, s2=None,
