@@ -20,3 +20,20 @@ for _ in range(20):
     brain.step += 1; brain.fit_batch(batch)
 pr.disable(); torch.cuda.synchronize()
 st = pstats.Stats(pr); st.sort_stats("tottime").print_stats(28)
+
+# the backward runs on autograd's worker thread, invisible to the profile above: wrap it
+from speech_anonymization_amd import convae as _cv
+_pr2 = cProfile.Profile()
+_orig = _cv._ConvAEFn.backward
+def _wrapped(ctx, *g):
+    _pr2.enable()
+    try:
+        return _orig(ctx, *g)
+    finally:
+        _pr2.disable()
+_cv._ConvAEFn.backward = staticmethod(_wrapped)
+for _ in range(20):
+    brain.step += 1; brain.fit_batch(batch)
+torch.cuda.synchronize()
+print("==== inside _ConvAEFn.backward (20 calls) ====")
+pstats.Stats(_pr2).sort_stats("tottime").print_stats(22)
