@@ -245,7 +245,8 @@ class _ConvAEFn(torch.autograd.Function):
         # activation cache: each conv also writes its transformed input rows in bf16, the operand
         # its weight gradient multiplies with (saves the recomputation and half of the bytes there)
         A = {}
-        cache_a = train and model.cache_wgrad_operand and ops.WGRAD_CODE[model.precision] in (L.BF16X1F, L.BF16)
+        cache_a = (train and model.cache_wgrad_operand and any(ctx.needs_input_grad)
+                   and ops.WGRAD_CODE[model.precision] in (L.BF16X1F, L.BF16))
 
         def cg(x, w, key, *args, **kw):
             if cache_a and key is not None and P[key].requires_grad:
