@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """bench.py -- throughput of the ConvAE + gender-adversarial train step on MI355X.
 
-  python bench.py --gpus N --steps K --warmup W          (N = 1 default)
+  python bench.py --gpus N --steps K --warmup W          (N = 1 default; N > 1 without a torchrun
+                                                          environment launches its own N ranks)
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
          --master-port P bench.py --gpus N --steps K --warmup W
 
@@ -9,27 +10,87 @@ One "step" = SexAnonymizationTraining.fit_batch on one synthetic 16 kHz batch pe
 scaling): Fbank x2 + InputNormalization x2 + ConvAutoencoder fwd + L1 recon / NLL losses +
 backward + clip_grad_norm_(5.0) + Adam + Noam (+ SyncBN statistic and gradient all-reduce on
 N > 1).  Workload = BASELINE.json configs[1]: recon 0.1 + sex 0.9 adversarial, shape M of
-SURVEY.md 8(d): B utterances of 161 120 samples -> T = 1008 frames each.  Inputs are resident in
-HBM when the timed region starts.  Prints ONE JSON line on rank 0.
+SURVEY.md 8(d): B utterances of 161 120 samples -> T = 1008 frames each (B = 32 is `value`; the
+B = 10 point of the same config is reported under config.b10).  Inputs are resident in HBM when
+the timed region starts.  Prints ONE JSON line on rank 0.
 """
 import argparse
 import json
 import os
+import socket
+import statistics
+import subprocess
 import sys
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-import torch  # noqa: E402
-
 HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
-MFMA_PEAK_TFLOPS = {"bf16": 2500.0, "bf16x3": 2500.0, "f32": 157.3}
+MFMA_PEAK_TFLOPS = {"bf16": 2500.0, "bf16x3": 2500.0, "f32": 157.3, "fp8": 5000.0}
+MFMA_PER_FLOP = {"bf16": 1, "bf16x3": 3, "f32": 1, "fp8": 1}      # executed MFMA flops per algorithmic flop
 N_SAMPLES = 161120               # -> T = 1 + N // 160 = 1008 frames (already a multiple of 36)
-BYTES_PER_FRAME = {"f32": 862400, "bf16x3": 862400, "bf16": 431200}       # SURVEY.md 8(d) algorithmic step traffic
+BYTES_PER_FRAME = {"f32": 862400, "bf16x3": 862400, "bf16": 431200, "fp8": 215600}   # SURVEY.md 8(d)
+SETUP_STEPS = 8                  # un-timed, before the contract's W warm-up steps (see run_config)
+KERNEL_T = {"bf16": "bf16", "bf16x3": "bf16x3_t", "f32": "float", "fp8": "fp8_t"}
+
+
+def parse_args(argv=None):
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=32,
+                    help="utterances per GPU of shape M (BASELINE.md config 2: B 10 and B 32)")
+    ap.add_argument("--dtype", default=os.environ.get("SA_BENCH_DTYPE", "bf16x3"),
+                    choices=["bf16x3", "bf16", "f32", "fp8"],
+                    help="bf16x3 (default): fp32 storage + split-bf16 operands on the bf16 MFMA, "
+                         "the mode that passes the 1e-4 parity tests; bf16: bf16 storage, single MFMA")
+    ap.add_argument("--samples", type=int, default=N_SAMPLES,
+                    help="waveform samples per utterance (default 161120 = shape M; 480000 = the 30 s shape XL)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-b10", action="store_true", help="skip the secondary B = 10 measurement")
+    ap.add_argument("--plumbing-only", action="store_true",
+                    help="launcher / rendezvous / max-over-ranks timing / JSON relay with the train step "
+                         "replaced by a sleep (CPU test of the N > 1 path; the line says so, it is NOT a measurement)")
+    ap.add_argument("--master-port", type=int, default=0)
+    return ap.parse_args(argv)
+
+
+# ------------------------------------------------------------------------------------------------
+# N > 1 without a torchrun environment: start the ranks ourselves.  Nothing here touches the GPU
+# (no HIP call, no torch.cuda.is_available()): the children are separate processes, never an exec
+# of a process that initialised the device.
+# ------------------------------------------------------------------------------------------------
+def self_launch(args, argv):
+    port = args.master_port
+    if not port:
+        with socket.socket() as s:
+            s.bind(("127.0.0.1", 0))
+            port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "4")
+    p = subprocess.Popen(cmd, stdout=subprocess.PIPE, env=env, text=True)
+    line = None
+    for ln in p.stdout:                     # relay rank 0's JSON line (and anything else) as it comes
+        sys.stdout.write(ln)
+        sys.stdout.flush()
+        if ln.lstrip().startswith("{") and '"metric"' in ln:
+            line = ln
+    rc = p.wait()
+    if rc != 0:
+        raise SystemExit(rc)
+    if line is None:
+        raise SystemExit("bench.py: the ranks exited without printing a result line")
+    return 0
 
 
 def build_brain(device, dtype_name, batch):
+    import functools
+    import torch
     import speech_anonymization_amd as pkg
     from speech_anonymization_amd import brain as B, convae, losses
     torch.manual_seed(8886)
@@ -43,7 +104,6 @@ def build_brain(device, dtype_name, batch):
         confusion_loss_weight=0.0, gradient_accumulation=1,
         noam_annealing=B.NoamScheduler(1.0, 25000, 768))
     hparams["epoch_counter"].current = 1
-    import functools
     adam_kw = dict(lr=0.001, betas=(0.9, 0.98), eps=1e-9)
     brain = B.SexAnonymizationTraining(
         modules={"normalize": pkg.InputNormalization("global", update_until_epoch=4)},
@@ -57,6 +117,7 @@ def build_brain(device, dtype_name, batch):
 
 def synthetic_batch(batch, rank, device, n_samples=None):
     """0.1*randn + 220 Hz / 1 kHz / 3.4 kHz sinusoids, clipped, seed 8886+rank."""
+    import torch
     from speech_anonymization_amd.brain import Batch
     g = torch.Generator(device="cpu").manual_seed(8886 + rank)
     n_samples = n_samples or N_SAMPLES
@@ -72,50 +133,49 @@ def synthetic_batch(batch, rank, device, n_samples=None):
     return Batch(wav, lens, gender)
 
 
-def cpu_baseline(threads):
-    """the oracle (CPU restatement of the reference step, same ATen kernels) on a bounded sample."""
+def cpu_model():
+    try:
+        for ln in open("/proc/cpuinfo"):
+            if ln.startswith("model name"):
+                return ln.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def cpu_baseline():
+    """the oracle (CPU restatement of the reference step, the same ATen CPU
+    kernels the reference executes) at shape M, B = 10, every core this process may use, 2 warm-up
+    steps + the median of 5 timed steps.  ~30 s of CPU work."""
+    import torch
     from oracle.train_step import OracleTrainer
     from oracle.features import synthetic_wave
-    Bc, steps = 4, 2
+    threads = len(os.sched_getaffinity(0))
+    Bc, warm, steps = 10, 2, 5
     tr = OracleTrainer(threads=threads)
     wav = synthetic_wave(Bc, N_SAMPLES, seed=8886)
     lens, gender = torch.ones(Bc), torch.arange(Bc) % 2
-    tr.fit_batch(wav, lens, gender)                       # warm-up
-    t0 = time.perf_counter()
-    for _ in range(steps):
+    for _ in range(warm):
         tr.fit_batch(wav, lens, gender)
-    dt = (time.perf_counter() - t0) / steps
+    ts = []
+    for _ in range(steps):
+        t0 = time.perf_counter()
+        tr.fit_batch(wav, lens, gender)
+        ts.append(time.perf_counter() - t0)
+    dt = statistics.median(ts)
     return {"value": Bc * 1008 / dt, "unit": "frames/s", "cores": threads, "kind": "port",
-            "sample": f"oracle train step (torch CPU fp32), B={Bc} x T=1008 frames, 1 warm-up + {steps} timed steps"}
+            "cpu_model": cpu_model(), "s_per_step": dt,
+            "sample": f"oracle train step (torch CPU fp32, {threads} threads), shape M: B={Bc} x T=1008 "
+                      f"frames, {warm} warm-up + median of {steps} timed steps"}
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--batch", type=int, default=32,
-                    help="utterances per GPU of shape M (BASELINE.md config 2: B 10 and B 32)")
-    ap.add_argument("--dtype", default=os.environ.get("SA_BENCH_DTYPE", "bf16x3"),
-                    choices=["bf16x3", "bf16", "f32"],
-                    help="bf16x3 (default): fp32 storage + split-bf16 operands on the bf16 MFMA, "
-                         "the mode that passes the 1e-4 parity tests; bf16: bf16 storage, single MFMA")
-    ap.add_argument("--samples", type=int, default=N_SAMPLES,
-                    help="waveform samples per utterance (default 161120 = shape M; 480000 = the 30 s shape XL)")
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    args = ap.parse_args()
-
-    from speech_anonymization_amd import distributed as sdist, ops
-    rank, local_rank, world = sdist.ddp_init_group()
-    if world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
-    device = torch.device("cuda", local_rank)
-    torch.cuda.set_device(device)
-
-    brain = build_brain(device, args.dtype, args.batch)
-    batch = synthetic_batch(args.batch, rank, device, args.samples)
-    T = 1 + args.samples // 160
-    T += (-T) % 36                                  # frames entering the ConvAE (padded to 36)
+def run_config(args, batch_size, rank, world, device, profile_key=None):
+    """SETUP_STEPS + args.warmup un-timed steps, then EXACTLY args.steps timed steps between
+    barrier + synchronize on both sides; returns (elapsed max over ranks, last loss, profile)."""
+    import torch
+    from speech_anonymization_amd import ops
+    brain = build_brain(device, args.dtype, batch_size)
+    batch = synthetic_batch(batch_size, rank, device, args.samples)
 
     def sync_all():
         if world > 1:
@@ -123,81 +183,160 @@ def main():
         torch.cuda.synchronize()
 
     # set-up, before the W warm-up steps of the contract: the first steps of a process pay one-time
-    # costs (code-object upload of ~60 kernels, allocator pools, operand-image tables, clock ramp)
-    for _ in range(8):
-        brain.step += 1
-        brain.fit_batch(batch)
-    for _ in range(args.warmup):
+    # costs (code-object upload of ~60 kernels, allocator pools, operand-image tables, clock ramp).
+    # Reported as "setup_steps"; not part of the timed region.
+    for _ in range(SETUP_STEPS + args.warmup):
         brain.step += 1
         brain.fit_batch(batch)
     sync_all()
-    ops.PROFILE.enable("conv_gemm(128,128,1,1)")          # dominant kernel: timed live with HIP events
+    if profile_key:
+        ops.PROFILE.enable(profile_key)               # dominant kernel: timed live with HIP events
     t0 = time.perf_counter()
     for _ in range(args.steps):
         brain.step += 1
         loss = brain.fit_batch(batch)
     sync_all()
     elapsed = time.perf_counter() - t0
-    prof = ops.PROFILE.collect()
+    prof = ops.PROFILE.collect() if profile_key else None
     if world > 1:
         tt = torch.tensor([elapsed], device=device, dtype=torch.float64)
         torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
         elapsed = float(tt)
+    return elapsed, float(loss), prof
+
+
+def roofline_of(prof, dtype):
+    """SURVEY 8(d) accounting for the dominant kernel family (sa_conv_gemm 128->128: encoder.11,
+    decoder.0, the three TDNN convolutions and their five data gradients):
+      algorithmic bytes = input rows + output rows once each (fp32 storage: 2 560 + 2 560 elements
+        per frame x 4 B) + on the data-gradient launches the stored forward tensor their fused
+        norm/activation-backward epilogue re-reads (8(d)'s "norm/act-bwd re-read");
+      algorithmic flops = 2 x MAC; the bf16x3 mode EXECUTES 3 MFMA flops per algorithmic flop.
+    frac_hbm = algorithmic bytes / launch time / 8 TB/s; frac_mfma = executed flops / launch time /
+    dense MFMA peak.  The binding roof is the one whose minimum time is larger; `frac` is the
+    fraction of THAT roof.  designed_bytes = what the kernel is built to move (adds the bf16
+    operand cache it writes and the second tensor of the fused apply prologue) -- informational."""
+    if not prof or not prof["launches"]:
+        return None
+    n = prof["launches"]
+    avg_s = prof["ms"] * 1e-3 / n
+    alg_b, des_b, flops = prof["alg_bytes"] / n, prof["bytes"] / n, prof["flops"] / n
+    mult = MFMA_PER_FLOP[dtype]
+    peak_tf = MFMA_PEAK_TFLOPS[dtype]
+    frac_hbm = alg_b / avg_s / 1e9 / HBM_PEAK_GBS
+    frac_mfma = flops * mult / avg_s / 1e12 / peak_tf
+    t_hbm, t_mfma = alg_b / (HBM_PEAK_GBS * 1e9), flops * mult / (peak_tf * 1e12)
+    if t_hbm >= t_mfma:
+        roof = {"bound": "hbm", "achieved": alg_b / avg_s / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": frac_hbm}
+    else:
+        roof = {"bound": "mfma", "achieved": flops * mult / avg_s / 1e12, "peak": peak_tf,
+                "unit": "TFLOP/s", "frac": frac_mfma}
+    roof.update({
+        "traffic": None, "kernel": "sa_conv_gemm_kernel<%s,128,128,1,1>" % KERNEL_T[dtype],
+        "launches_timed": n, "avg_us": avg_s * 1e6,
+        "algorithmic_bytes": alg_b, "algorithmic_flops": flops, "designed_bytes": des_b,
+        "frac_hbm": frac_hbm, "frac_mfma": frac_mfma,
+        "roof_time_us": {"hbm": t_hbm * 1e6, "mfma": t_mfma * 1e6},
+        "mfma_flops_executed_per_algorithmic_flop": mult,
+        "hbm_gbs": alg_b / avg_s / 1e9, "tflops_algorithmic": flops / avg_s / 1e12,
+        "tflops_executed": flops * mult / avg_s / 1e12})
+    return roof
+
+
+def attach_pmc_traffic(roof, dtype, batch):
+    """HBM bytes per launch of the same kernel from the rocprofv3 --pmc passes of this config
+    (tools/pmc_traffic.py writes profiles/pmc_traffic.json; FETCH_SIZE x2 correction, WRITE_SIZE).
+    A separate profiled run, not this process: the source is named beside the number."""
+    try:
+        pm = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
+        key = "%s:B%d:sa_conv_gemm_kernel<%s,128,128,1,1>" % (dtype, batch, KERNEL_T[dtype])
+        if key in pm:
+            roof["traffic"] = pm[key]["total_bytes"]
+            roof["traffic_source"] = pm[key].get("source", "profiles/pmc_traffic.json (rocprofv3 --pmc, separate run)")
+            roof["traffic_over_algorithmic"] = pm[key]["total_bytes"] / roof["algorithmic_bytes"]
+    except Exception:
+        pass
+
+
+def main(argv=None):
+    argv = sys.argv[1:] if argv is None else list(argv)
+    args = parse_args(argv)
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        return self_launch(args, argv)
+
+    import torch
+    from speech_anonymization_amd import distributed as sdist
+    rank, local_rank, world = sdist.ddp_init_group()
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    backend = torch.distributed.get_backend() if world > 1 else "none"
+    ranks_seen = torch.distributed.get_world_size() if world > 1 else 1
+    T = 1 + args.samples // 160
+    T += (-T) % 36                                  # frames entering the ConvAE (padded to 36)
+
+    if args.plumbing_only:
+        # the N > 1 path without the GPU step: rendezvous, barriers, max-over-ranks, JSON on rank 0
+        torch.distributed.barrier() if world > 1 else None
+        t0 = time.perf_counter()
+        time.sleep(0.01 * args.steps * (1 + rank))          # ranks differ: MAX must pick the slowest
+        torch.distributed.barrier() if world > 1 else None
+        elapsed = time.perf_counter() - t0
+        if world > 1:
+            tt = torch.tensor([elapsed], dtype=torch.float64)
+            torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
+            elapsed = float(tt)
+        if rank == 0:
+            print(json.dumps({"metric": "audio frames/sec (node), ConvAE+gender-adv train step",
+                              "value": None, "plumbing_only": True, "n_gpus": world, "steps": args.steps,
+                              "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
+                              "ranks_seen": ranks_seen, "backend": backend}), flush=True)
+        if world > 1:
+            torch.distributed.barrier()
+            torch.distributed.destroy_process_group()
+        return 0
+
+    device = torch.device("cuda", local_rank)
+    torch.cuda.set_device(device)
+
+    elapsed, loss, prof = run_config(args, args.batch, rank, world, device,
+                                     profile_key="conv_gemm(128,128,1,1)")
     frames = world * args.batch * T * args.steps
     value = frames / elapsed
+    b10 = None
+    if not args.no_b10 and args.batch != 10 and args.samples == N_SAMPLES:
+        e10, l10, _ = run_config(args, 10, rank, world, device)
+        b10 = {"batch_per_gpu": 10, "value": world * 10 * T * args.steps / e10, "unit": "frames/s",
+               "ms_per_step": e10 / args.steps * 1e3, "loss": l10}
 
     if rank == 0:
-        esz = 2 if args.dtype == "bf16" else 4
-        mfma_mult = 3 if args.dtype == "bf16x3" else 1     # executed MFMA flops per algorithmic flop
-        roof = None
-        if prof["launches"]:
-            avg_s = prof["ms"] * 1e-3 / prof["launches"]
-            nbytes, flops = prof["bytes"] / prof["launches"], prof["flops"] / prof["launches"]
-            # bf16x3 executes 3 bf16 MFMA flops per algorithmic flop (hi*hi + lo*hi + hi*lo), so the
-            # MFMA ceiling for ALGORITHMIC flops in that mode is the dense bf16 peak / 3
-            mfma_peak = MFMA_PEAK_TFLOPS[args.dtype] / mfma_mult
-            t_hbm, t_mfma = nbytes / (HBM_PEAK_GBS * 1e9), flops / (mfma_peak * 1e12)
-            if t_hbm >= t_mfma:
-                roof = {"bound": "hbm", "achieved": nbytes / avg_s / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s"}
-            else:
-                roof = {"bound": "mfma", "achieved": flops / avg_s / 1e12, "peak": mfma_peak, "unit": "TFLOP/s"}
-            roof["frac"] = roof["achieved"] / roof["peak"]
-            roof["traffic"] = None
-            try:                                   # PMC pass (tools/pmc_traffic.py), same config only
-                pm = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
-                key = "%s:B%d:sa_conv_gemm_kernel<%s,128,128,1,1>" % (
-                    args.dtype, args.batch, {"bf16": "bf16", "bf16x3": "bf16x3_t", "f32": "float"}[args.dtype])
-                if key in pm:
-                    roof["traffic"] = pm[key]["total_bytes"]
-                    roof["algorithmic_bytes"] = nbytes
-            except Exception:
-                pass
-            roof["kernel"] = "sa_conv_gemm_kernel<%s,128,128,1,1>" % {"bf16": "bf16", "bf16x3": "bf16x3_t", "f32": "float"}[args.dtype]
-            roof["mfma_flops_executed_per_algorithmic_flop"] = mfma_mult
-            roof["avg_us"] = avg_s * 1e6
-            roof["hbm_gbs"] = nbytes / avg_s / 1e9
-            roof["tflops"] = flops / avg_s / 1e12
+        roof = roofline_of(prof, args.dtype)
+        if roof:
+            attach_pmc_traffic(roof, args.dtype, args.batch)
         out = {
             "metric": "audio frames/sec (node), ConvAE+gender-adv train step", "value": value,
             "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "setup_steps": SETUP_STEPS,
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+            "ranks_seen": ranks_seen, "backend": backend,
             "config": {"workload": "ConvAE recon0.1+sex0.9 adversarial train step (L1 recon + NLL), "
                                    f"shape {'M' if args.samples == N_SAMPLES else 'custom'}: {args.batch} utt/GPU x "
                                    f"{args.samples} samples (T={T} frames), "
                                    "Fbank x2 + norm + fwd + bwd + clip + Adam + Noam",
                        "batch_per_gpu": args.batch, "frames_per_utt": T, "parallelism": f"dp{world}",
-                       "loss": float(loss)},
+                       "loss": loss, "b10": b10},
             "step_hbm_roofline_frac": value * BYTES_PER_FRAME[args.dtype] / (world * HBM_PEAK_GBS * 1e9),
             "roofline": roof,
         }
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(min(16, len(os.sched_getaffinity(0))))
-        print(json.dumps(out))
+            out["cpu_baseline"] = cpu_baseline()
+        print(json.dumps(out), flush=True)
     if world > 1:
         torch.distributed.barrier()
         torch.distributed.destroy_process_group()
+    return 0
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main())

@@ -167,16 +167,21 @@ int sa_sum_partials(const float* slabs, double* dst, int nbatch, int nslab, int 
 int sa_sum_rows_d(const double* src, double* dst, int R, int n, void* stream);
 int sa_fin_in_fwd(const double* sums, int B, int C, int n, const float* gamma, const float* beta,
                   float eps, float* mean, float* rstd, float* scale, float* shift, void* stream);
-/* sums of the BatchNorm finalisers may be R partial rows ([R][groups][2], added in row order) */
+/* sums of the BatchNorm finalisers may be R partial rows ([R][groups][2], added in row order).
+ * count_dev / n_dev (optional, device fp64 scalar): the element count is read ON THE DEVICE and the
+ * host value is ignored -- SyncBatchNorm over ranks with ragged batches all-reduces the per-rank
+ * counts beside the sums (torch.nn.SyncBatchNorm exchanges counts the same way) without a host
+ * round trip. */
 int sa_fin_bn_fwd(const double* sums, int R, int C, double count, const float* gamma, const float* beta,
                   float eps, float momentum, float* run_mean, float* run_var, float* mean,
-                  float* rstd, float* scale, float* shift, void* stream);
+                  float* rstd, float* scale, float* shift, const double* count_dev, void* stream);
 int sa_fin_bn_eval(int C, const float* gamma, const float* beta, float eps, const float* run_mean,
                    const float* run_var, float* mean, float* rstd, float* scale, float* shift,
                    void* stream);
 int sa_fin_norm_bwd(const double* sums, const double* lsums, int R, int groups, int C, double n,
                     const float* gamma, const float* mean, const float* rstd, float sign, float* c1,
-                    float* c2, float* c3, float* dgamma, float* dbeta, void* stream);
+                    float* c2, float* c3, float* dgamma, float* dbeta, const double* n_dev,
+                    void* stream);
 int sa_fin_bias(const double* sums, int B, int C, int ncomp, float* db, void* stream);  /* sums [B][C][ncomp] */
 
 /* ---- classifier head + losses (sa_head.hip): TDNNSexClassifier.forward reshape + pooling
@@ -202,7 +207,7 @@ int sa_colsums(const float* X, const float* H, const float* hmean, const float* 
                double* sums, void* stream);
 int sa_bn2d_bwd(const float* G, const float* H, const double* sums, double count, const float* gamma,
                 const float* mean, const float* rstd, int relu_mask, int M, int N, float* dH,
-                void* stream);
+                const double* count_dev, void* stream);
 int sa_dense_wgrad(const float* dY, const float* X, const float* ps, const float* pt, int M, int N,
                    int K, float* dW, void* stream);
 int sa_log_softmax(const float* X, float* Y, int M, int N, void* stream);

@@ -23,7 +23,7 @@ def noam_lr(n_steps, lr_initial=1.0, n_warmup=25000, model_size=768):
 class OracleTrainer:
     def __init__(self, params=None, recon_w=0.1, sex_w=0.9, util_w=0.0, conf_w=0.0,
                  recon_kind="l1", model_type="convae", max_grad_norm=5.0,
-                 top_db_mode="utterance", threads=None):
+                 top_db_mode="utterance", threads=None, epoch_parity_schedule=False):
         if threads:
             torch.set_num_threads(threads)
         self.model = ConvAutoencoder()
@@ -38,6 +38,20 @@ class OracleTrainer:
                                     eps=1e-9)
         self.n_steps = 0
         self.epoch = 1
+        self.epoch_parity_schedule = epoch_parity_schedule
+
+    def apply_epoch_schedule(self):
+        """HEAD's fit_batch preamble (speechbrain_convae_train.py:212-235): even epoch -> recon 0 /
+        sex 0.8 / utility 0.2 / confusion 0, classifier frozen; odd epoch -> sex 0.5 only,
+        everything but the classifier frozen.  (The utility term needs the frozen ASR, which is
+        outside this path: its loss value is 0 here, the weight is still set.)"""
+        joint = self.epoch % 2 == 0
+        if joint:
+            self.w.update(recon=0.0, sex=0.8, utility=0.2, confusion=0.0)
+        else:
+            self.w.update(recon=0.0, sex=0.5, utility=0.0)
+        for name, p in self.model.named_parameters():
+            p.requires_grad = ("sex_classifier" not in name) if joint else ("sex_classifier" in name)
 
     def feats(self, wavs, lens):
         f = self.fbank(wavs)
@@ -56,13 +70,20 @@ class OracleTrainer:
                           recon_loss=rl, sex_loss=sl, confusion_loss=cl)
 
     def fit_batch(self, wavs, lens, gender):
+        if self.epoch_parity_schedule:
+            self.apply_epoch_schedule()
         loss, aux = self.forward_loss(wavs, lens, gender)
         loss.backward()
-        aux["grads"] = {k: p.grad.detach().clone() for k, p in self.model.named_parameters()}
-        aux["grad_norm"] = torch.nn.utils.clip_grad_norm_(self.model.parameters(),
-                                                          self.max_grad_norm)
+        aux["grads"] = {k: (p.grad.detach().clone() if p.grad is not None else None)
+                        for k, p in self.model.named_parameters()}
+        aux["grad_norm"] = torch.nn.utils.clip_grad_norm_(
+            [p for p in self.model.parameters() if p.grad is not None], self.max_grad_norm)
         self.opt.step()
-        self.opt.zero_grad()
+        # torch 1.10 (the reference's pin, results/*/env.log): optimizer.zero_grad() defaults to
+        # set_to_none=False, i.e. gradients stay allocated as zeros -- so a parameter frozen by the
+        # epoch-parity schedule AFTER it has had a gradient is still updated by Adam (zero
+        # gradient, non-zero moments).  Spelled out here because torch >= 2.0 changed the default.
+        self.opt.zero_grad(set_to_none=False)
         self.n_steps += 1
         lr = noam_lr(self.n_steps)
         for g in self.opt.param_groups:

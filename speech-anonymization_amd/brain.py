@@ -90,6 +90,11 @@ class Brain:
     def __init__(self, modules=None, opt_class=None, hparams=None, run_opts=None, checkpointer=None):
         run_opts = dict(run_opts or {})
         self.device = torch.device(run_opts.get("device", "cuda:0" if torch.cuda.is_available() else "cpu"))
+        if self.device.type == "cuda":
+            # the HIP library launches on torch's CURRENT device / stream: `--device cuda:1` in one
+            # process (the reference's CLI) must make that device current, on this thread and -- via
+            # the tensors' device -- on autograd's
+            torch.cuda.set_device(self.device)
         self.max_grad_norm = float(run_opts.get("max_grad_norm", 5.0))
         self.nonfinite_patience = int(run_opts.get("nonfinite_patience", 3))
         self.lazy_finite_check = bool(run_opts.get("lazy_finite_check", True))
@@ -115,8 +120,15 @@ class Brain:
         pass
 
     def on_fit_start(self):
+        """speechbrain order: modules to the device, optimizer, then resume from the newest
+        checkpoint if the output folder holds one (all ranks; model, scheduler, normaliser, epoch
+        counter, optimizer moments -- reference checkpoints carry optimizer.ckpt too)."""
         self.modules.to(self.device)
         self.init_optimizers()
+        if self.checkpointer is not None:
+            if self.optimizer is not None:
+                self.checkpointer.add_recoverable("optimizer", self.optimizer)
+            self.resumed_from = self.checkpointer.recover_if_possible(device=self.device, brain=self)
 
     def init_optimizers(self):
         if self.opt_class is not None and self.optimizer is None:
@@ -170,10 +182,18 @@ class Brain:
         return self.compute_objectives(out, batch, stage=stage).detach()
 
     def update_average(self, loss, avg_loss):
-        if torch.isfinite(loss):
-            avg_loss -= avg_loss / self.step
-            avg_loss += float(loss) / self.step
-        return avg_loss
+        """running mean of the finite losses (speechbrain's update_average), kept ON THE DEVICE:
+        reading the loss on the host every step would stall the CPU until the whole backward has
+        finished -- the stall lazy_finite_check avoids.  It is read once, at the end of the epoch."""
+        if not loss.is_cuda:
+            if torch.isfinite(loss):
+                avg_loss -= avg_loss / self.step
+                avg_loss += float(loss) / self.step
+            return avg_loss
+        if not torch.is_tensor(avg_loss):
+            avg_loss = torch.full((), float(avg_loss), device=loss.device, dtype=torch.float32)
+        new = avg_loss + (loss.detach().float() - avg_loss) / self.step
+        return torch.where(torch.isfinite(loss), new, avg_loss)
 
     def fit(self, epoch_counter, train_set, valid_set=None, progressbar=False, **_):
         self.on_fit_start()
@@ -187,6 +207,7 @@ class Brain:
                 self.step += 1
                 loss = self.fit_batch(batch)
                 self.avg_train_loss = self.update_average(loss, self.avg_train_loss)
+            self.avg_train_loss = float(self.avg_train_loss)          # the epoch's one host read
             self.on_stage_end(Stage.TRAIN, self.avg_train_loss, epoch)
             if valid_set is not None:
                 self.on_stage_start(Stage.VALID, epoch)
@@ -273,12 +294,32 @@ class SexAnonymizationTraining(Brain):
         for name, param in self.modules.ConvAE.named_parameters():
             param.requires_grad = ("sex_classifier" not in name) if joint else ("sex_classifier" in name)
 
+    def _zero_grads_of_frozen(self):
+        """torch 1.10's optimizer.zero_grad() (the reference's pin; set_to_none=False by default)
+        leaves zero-filled gradients behind, so a parameter the epoch-parity schedule freezes AFTER
+        it has had a gradient keeps being updated by Adam on its moments.  Gradients are dropped
+        (set to None) here so that autograd adopts the kernels' bucket views without a copy; the
+        zero gradient of a frozen parameter with optimizer state is put back just before step()."""
+        st = self.optimizer.state
+        for group in self.optimizer.param_groups:
+            for p in group["params"]:
+                if p.grad is None and not p.requires_grad and p in st and len(st[p]):
+                    z = getattr(self, "_zero_grad_cache", None)
+                    if z is None:
+                        z = self._zero_grad_cache = {}
+                    g = z.get(p)
+                    if g is None:
+                        g = z[p] = torch.zeros_like(p)
+                    p.grad = g
+
     def fit_batch(self, batch):
         self.apply_epoch_schedule()
         predictions = self.compute_forward(batch, Stage.TRAIN)
         loss = self.compute_objectives(predictions, batch, Stage.TRAIN)
         (loss / self.hparams.gradient_accumulation).backward()
         if self.step % self.hparams.gradient_accumulation == 0:
+            if getattr(self.hparams, "epoch_parity_schedule", False):
+                self._zero_grads_of_frozen()
             self.check_gradients(loss)          # return value ignored, like the reference (:249-251)
             self.optimizer.step()
             self.optimizer.zero_grad()
@@ -323,7 +364,7 @@ class FileTrainLogger:
     def _fmt(d):
         out = []
         for k, v in d.items():
-            if isinstance(v, float) and 1.0 < abs(v) < 100.0:
+            if isinstance(v, float) and 1.0 < v < 100.0:      # speechbrain: no abs(); negatives go to %.2e
                 v = f"{v:.2f}"
             elif isinstance(v, float):
                 v = f"{v:.2e}"

@@ -115,10 +115,19 @@ class ConvAutoencoder(nn.Module):
         self.sync_bn = sync_bn
 
     def forward(self, feats):
-        c = getattr(self, "_np_cache", None)          # walking the module tree costs ~0.15 ms a call
-        if c is None or c[2] is not self.encoder[0].weight or c[3] is not self.decoder[6].bias:
-            names, params = zip(*self.named_parameters())
-            c = self._np_cache = (names, params, self.encoder[0].weight, self.decoder[6].bias)
+        # walking the module tree costs ~0.15 ms a call: the (names, parameters) lists are cached
+        # and revalidated against the owners' registries (56 identity checks, ~5 us), so replacing
+        # ANY parameter object (load into a sub-module, .to(), pruning, ...) is noticed
+        c = self.__dict__.get("_np_cache")
+        if c is None or any(o[n] is not p for o, n, p in c[2]):
+            names, params, owners = [], [], []
+            for mname, mod in self.named_modules():
+                for pname, p in mod._parameters.items():
+                    if p is not None:
+                        names.append(f"{mname}.{pname}" if mname else pname)
+                        params.append(p)
+                        owners.append((mod._parameters, pname, p))
+            c = self.__dict__["_np_cache"] = (tuple(names), tuple(params), owners)
         return _ConvAEFn.apply(self, c[0], feats, *c[1])
 
     def _wgrad_stream(self, device):
@@ -143,6 +152,27 @@ class ConvAutoencoder(nn.Module):
             dist.all_reduce(sums)
             return dist.get_world_size()
         return 1
+
+    def _bn_global_counts(self, counts, device):
+        """SyncBatchNorm element counts.  Ranks hold ragged batches (data.batches pads each rank's
+        batch to its own longest utterance, the last batch may be short), so the per-layer counts
+        are all-reduced beside the sums -- torch.nn.SyncBatchNorm, which speechbrain applies for
+        the reference under DDP, exchanges counts the same way.  ONE collective per step for the
+        six BatchNorms; the result stays on the device (the finalisers read it there:
+        sa_fin_bn_fwd / sa_fin_norm_bwd / sa_bn2d_bwd `count_dev`).  None on a single process."""
+        if not self._bn_syncs():
+            return None
+        import torch.distributed as dist
+        key = (tuple(counts), str(device))
+        cache = self.__dict__.setdefault("_count_cache", {})
+        local = cache.get(key)
+        if local is None:
+            if len(cache) > 64:
+                cache.clear()
+            local = cache[key] = torch.tensor(counts, dtype=torch.float64).to(device)
+        g = local.clone()
+        dist.all_reduce(g)
+        return g
 
     def _bn_rows(self):
         """per-utterance partial rows may go straight to the finalisers when nothing is all-reduced"""
@@ -257,19 +287,25 @@ class _ConvAEFn(torch.autograd.Function):
             sums = ops.sum_partials(stats, B)
             return ops.fin_in_fwd(sums, B, C, n, P[prefix + ".weight"], P[prefix + ".bias"])
 
-        def bnorm(sums, count, mod, prefix, C):
-            """sums [C,2] local; returns (mean, rstd, scale, shift) per channel."""
+        def bnorm(sums, count, mod, prefix, C, ci):
+            """sums [C,2] local; returns (mean, rstd, scale, shift) per channel.  ci: index of
+            this BatchNorm in the all-reduced count vector gc (SyncBatchNorm)."""
             if not train:
                 return ops.fin_bn_eval(C, P[prefix + ".weight"], P[prefix + ".bias"],
                                        mod.running_mean, mod.running_var)
-            w = model._bn_allreduce(sums)
-            out = ops.fin_bn_fwd(sums, C, count * w, P[prefix + ".weight"], P[prefix + ".bias"],
-                                 mod.running_mean, mod.running_var)
+            model._bn_allreduce(sums)
+            out = ops.fin_bn_fwd(sums, C, count, P[prefix + ".weight"], P[prefix + ".bias"],
+                                 mod.running_mean, mod.running_var, count_dev=cdev(ci))
             tracked.append(mod.num_batches_tracked)
             return out
 
         tracked = []                                            # BatchNorm step counters, bumped together
         enc, dec, cls = model.encoder, model.decoder, model.sex_classifier
+        La, Lb, Lc = L4 - 4, L4 - 8, L4 - 14
+        # global element counts of the six BatchNorms (norm, tdnn.2/5/8, classify.2/5) under
+        # SyncBatchNorm: one tiny all-reduce, device-resident; None on one process
+        gc = model._bn_global_counts([B * L4, B * La, B * Lb, B * Lc, B, B], feats.device) if train else None
+        cdev = lambda i: None if gc is None else gc[i:i + 1]
         # ---------------- encoder ----------------
         y0 = ops.conv1toC(x0, P["encoder.0.weight"], P["encoder.0.bias"], dt)
         y1, st = cg(y0, pw("encoder.2.weight", "conv_fwd"), "encoder.2.weight", P["encoder.2.bias"], 32, 64, 2, 1,
@@ -292,28 +328,27 @@ class _ConvAEFn(torch.autograd.Function):
             y5, a4_stats = y5
         # ---------------- sex classifier (GradReverse = identity forward) ----------------
         sums = ops.sum_partials(a4_stats, 1, rows=model._bn_rows()) if train else None
-        bn_n = bnorm(sums, B * L4, cls.norm, "sex_classifier.norm", 128)
-        La, Lb, Lc = L4 - 4, L4 - 8, L4 - 14
+        bn_n = bnorm(sums, B * L4, cls.norm, "sex_classifier.norm", 128, 0)
         r0, st = cg(y4, pw("sex_classifier.tdnn.0.weight", "conv_fwd"), "sex_classifier.tdnn.0.weight",
                                P["sex_classifier.tdnn.0.bias"], 128, 128, 1, 1, ops.taps_conv(5, 1, 0), La,
                                s1=n4[2], t1=n4[3], swish=True, s2=bn_n[2], t2=bn_n[3], relu=True,
                                want_stats=True)
-        bn0 = bnorm(ops.sum_partials(st, 1, rows=model._bn_rows()), B * La, cls.tdnn[2], "sex_classifier.tdnn.2", 128)
+        bn0 = bnorm(ops.sum_partials(st, 1, rows=model._bn_rows()), B * La, cls.tdnn[2], "sex_classifier.tdnn.2", 128, 1)
         r1, st = cg(r0, pw("sex_classifier.tdnn.3.weight", "conv_fwd"), "sex_classifier.tdnn.3.weight",
                                P["sex_classifier.tdnn.3.bias"], 128, 128, 1, 1, ops.taps_conv(3, 2, 0), Lb,
                                s2=bn0[2], t2=bn0[3], relu=True, want_stats=True)
-        bn1 = bnorm(ops.sum_partials(st, 1, rows=model._bn_rows()), B * Lb, cls.tdnn[5], "sex_classifier.tdnn.5", 128)
+        bn1 = bnorm(ops.sum_partials(st, 1, rows=model._bn_rows()), B * Lb, cls.tdnn[5], "sex_classifier.tdnn.5", 128, 2)
         r2, st = cg(r1, pw("sex_classifier.tdnn.6.weight", "conv_fwd"), "sex_classifier.tdnn.6.weight",
                                P["sex_classifier.tdnn.6.bias"], 128, 128, 1, 1, ops.taps_conv(3, 3, 0), Lc,
                                s2=bn1[2], t2=bn1[3], relu=True, want_stats=True)
-        bn2 = bnorm(ops.sum_partials(st, 1, rows=model._bn_rows()), B * Lc, cls.tdnn[8], "sex_classifier.tdnn.8", 128)
+        bn2 = bnorm(ops.sum_partials(st, 1, rows=model._bn_rows()), B * Lc, cls.tdnn[8], "sex_classifier.tdnn.8", 128, 3)
         pooled, pmean, psd = ops.pool_fwd(r2, bn2[2], bn2[3], noise=_noise(model, B, feats.device))
         H1 = ops.dense(pooled, P["sex_classifier.classify.0.weight"], P["sex_classifier.classify.0.bias"],
                        128, 256, relu=True)
-        f1 = bnorm(ops.colsums(H1) if train else None, B, cls.classify[2], "sex_classifier.classify.2", 128)
+        f1 = bnorm(ops.colsums(H1) if train else None, B, cls.classify[2], "sex_classifier.classify.2", 128, 4)
         H2 = ops.dense(H1, P["sex_classifier.classify.3.weight"], P["sex_classifier.classify.3.bias"],
                        64, 128, ps=f1[2], pt=f1[3], relu=True)
-        f2 = bnorm(ops.colsums(H2) if train else None, B, cls.classify[5], "sex_classifier.classify.5", 64)
+        f2 = bnorm(ops.colsums(H2) if train else None, B, cls.classify[5], "sex_classifier.classify.5", 64, 5)
         logits = ops.dense(H2, P["sex_classifier.classify.6.weight"], P["sex_classifier.classify.6.bias"],
                            2, 64, ps=f2[2], pt=f2[3])
         logp = ops.log_softmax(logits)
@@ -333,7 +368,7 @@ class _ConvAEFn(torch.autograd.Function):
         S.update(x0=x0, y=[y0, y1, y2, y3, y4, y5, y6, y7, y8], r=[r0, r1, r2],
                  n=[None, n1, n2, n3, n4, None, n6, None, n8], bn=[bn_n, bn0, bn1, bn2], f=[f1, f2],
                  pooled=pooled, pmean=pmean, psd=psd, H1=H1, H2=H2, logp=logp,
-                 dims=(B, T, Ltot, L2, L4, La, Lb, Lc), train=train, W=W, A=A)
+                 dims=(B, T, Ltot, L2, L4, La, Lb, Lc), train=train, W=W, A=A, gc=gc)
         ctx.S, ctx.model, ctx.names, ctx.params = S, model, names, params
         ctx.need_input_grad = feats.requires_grad
         return recon.view(B, T, Fd), logp
@@ -356,12 +391,21 @@ class _ConvAEFn(torch.autograd.Function):
         dev = y0.device
         G = {k: None for k in names}
         need = {k: p.requires_grad for k, p in P.items()}
+        # which stages have anything to produce (the epoch-parity schedule of the reference freezes
+        # either the classifier or everything else, speechbrain_convae_train.py:212-235): like
+        # autograd in the reference, nothing is computed below the last tensor that needs a gradient
+        need_stage = {st: any(v for k, v in need.items() if k.startswith(st))
+                      for st in sdist.StageBuckets.STAGES}
+        run_encoder = need_stage["encoder"] or ctx.need_input_grad
+        run_decoder = need_stage["decoder"] or run_encoder
         buckets = sdist.StageBuckets(list(P.items()), dev, model._side_stream(dev))
         newg = buckets.view
 
         def setg(key, val):
             G[key] = newg(key).copy_(val.reshape(P[key].shape))
         W, A = S["W"], S["A"]
+        gc = S["gc"]                                      # all-reduced BatchNorm counts (or None)
+        cdev = lambda i: None if gc is None else gc[i:i + 1]
         pw = lambda k, kind: W[(k, kind)]
         wg = functools.partial(ops.wgrad, code=ops.WGRAD_CODE[model.precision])
         # with the bf16 operand caches in place the apply pass of every normalised layer whose
@@ -423,17 +467,18 @@ class _ConvAEFn(torch.autograd.Function):
                 d.update(s1=xp[0], t1=xp[1], xp_is_act=True)
             return d
 
-        def bn_finish(g, st, r, bn, Ln, prefix, bias_key, xp=None):
+        def bn_finish(g, st, r, bn, Ln, prefix, bias_key, ci, xp=None):
             """backward of [conv -> ReLU -> BatchNorm(prefix)] w.r.t. the conv output (stored r =
             relu output); xp=(s1,t1): the BN input is swish(r*s1+t1) instead (the `norm` BN on the
             encoder output, with GradReverse in front: sign -1, no ReLU mask)."""
             mean, rstd = bn[0], bn[1]
             kw = dict(s1=xp[0], t1=xp[1], xp_is_act=True) if xp else {}
             lsums = ops.sum_partials(st, 1, rows=model._bn_rows())
-            gsums, w = model._bn_global(lsums)
+            gsums, _ = model._bn_global(lsums)
             dg, db = newg(prefix + ".weight"), newg(prefix + ".bias")
-            c1, c2, c3 = ops.fin_norm_bwd(gsums, lsums, 128, 128, float(B * Ln * w), P[prefix + ".weight"],
-                                          mean, rstd, sign=-1.0 if xp else 1.0, dgamma=dg, dbeta=db)
+            c1, c2, c3 = ops.fin_norm_bwd(gsums, lsums, 128, 128, float(B * Ln), P[prefix + ".weight"],
+                                          mean, rstd, sign=-1.0 if xp else 1.0, dgamma=dg, dbeta=db,
+                                          n_dev=cdev(ci))
             G[prefix + ".weight"], G[prefix + ".bias"] = dg, db
             if fuse:
                 return _PendingApply(g, r, (c1, c2, c3), True, not xp, bias_key)
@@ -503,37 +548,45 @@ class _ConvAEFn(torch.autograd.Function):
         G[c + "6.weight"] = ops.dense_wgrad(dLG, H2, newg(c + "6.weight"), ps=f2[2], pt=f2[3])
         setg(c + "6.bias", ops.colsums(dLG)[:, 0])
         dN2 = ops.dense(dLG, P[c + "6.weight"], None, 64, 2, transpose_w=True)
-        l2 = ops.colsums(dN2, H2, f2[0], f2[1]); g2s, w = model._bn_global(l2)
+        l2 = ops.colsums(dN2, H2, f2[0], f2[1]); g2s, _ = model._bn_global(l2)
         setg(c + "5.weight", l2[:, 1]); setg(c + "5.bias", l2[:, 0])
-        dH2 = ops.bn2d_bwd(dN2, H2, g2s, B * w, P[c + "5.weight"], f2[0], f2[1], True)
+        dH2 = ops.bn2d_bwd(dN2, H2, g2s, B, P[c + "5.weight"], f2[0], f2[1], True, count_dev=cdev(5))
         G[c + "3.weight"] = ops.dense_wgrad(dH2, H1, newg(c + "3.weight"), ps=f1[2], pt=f1[3])
         setg(c + "3.bias", ops.colsums(dH2)[:, 0])
         dN1 = ops.dense(dH2, P[c + "3.weight"], None, 128, 64, transpose_w=True)
-        l1 = ops.colsums(dN1, H1, f1[0], f1[1]); g1s, w = model._bn_global(l1)
+        l1 = ops.colsums(dN1, H1, f1[0], f1[1]); g1s, _ = model._bn_global(l1)
         setg(c + "2.weight", l1[:, 1]); setg(c + "2.bias", l1[:, 0])
-        dH1 = ops.bn2d_bwd(dN1, H1, g1s, B * w, P[c + "2.weight"], f1[0], f1[1], True)
+        dH1 = ops.bn2d_bwd(dN1, H1, g1s, B, P[c + "2.weight"], f1[0], f1[1], True, count_dev=cdev(4))
         G[c + "0.weight"] = ops.dense_wgrad(dH1, S["pooled"], newg(c + "0.weight"))
         setg(c + "0.bias", ops.colsums(dH1)[:, 0])
         dP = ops.dense(dH1, P[c + "0.weight"], None, 256, 128, transpose_w=True)
         t = "sex_classifier.tdnn."
         g, st = ops.pool_bwd(r2, bn2[2], bn2[3], dP, S["pmean"], S["psd"], bn=(bn2[0], bn2[1]))
-        g = bn_finish(g, st, r2, bn2, Lc, t + "8", t + "6.bias")
+        g = bn_finish(g, st, r2, bn2, Lc, t + "8", t + "6.bias", 3)
         conv_wgrad(t + "6.weight", r1, g, 128, 128, 1, Lc, 3, 3, 0, s2=bn1[2], t2=bn1[3])
         g, st = cg(g, pw(t + "6.weight", "conv_dgrad"), None, 128, 128, 1, 1,
                    ops.taps_conv_dgrad_s1(3, 3, 0), Lb, want_stats=True, ep=bn_ep(r1, bn1))
-        g = bn_finish(g, st, r1, bn1, Lb, t + "5", t + "3.bias")
+        g = bn_finish(g, st, r1, bn1, Lb, t + "5", t + "3.bias", 2)
         conv_wgrad(t + "3.weight", r0, g, 128, 128, 1, Lb, 3, 2, 0, s2=bn0[2], t2=bn0[3])
         g, st = cg(g, pw(t + "3.weight", "conv_dgrad"), None, 128, 128, 1, 1,
                    ops.taps_conv_dgrad_s1(3, 2, 0), La, want_stats=True, ep=bn_ep(r0, bn0))
-        g = bn_finish(g, st, r0, bn0, La, t + "2", t + "0.bias")
+        g = bn_finish(g, st, r0, bn0, La, t + "2", t + "0.bias", 1)
         conv_wgrad(t + "0.weight", y4, g, 128, 128, 1, La, 5, 1, 0, s1=n4[2], t1=n4[3], swish=True,
                    s2=bn_n[2], t2=bn_n[3])
         xp4 = (n4[2], n4[3])
         g, st = cg(g, pw(t + "0.weight", "conv_dgrad"), None, 128, 128, 1, 1,
                    ops.taps_conv_dgrad_s1(5, 1, 0), L4, want_stats=True, ep=bn_ep(y4, bn_n, xp4))
-        da4_cls = bn_finish(g, st, y4, bn_n, L4, "sex_classifier.norm", None, xp=xp4)      # includes GRL
+        da4_cls = bn_finish(g, st, y4, bn_n, L4, "sex_classifier.norm", None, 0, xp=xp4)      # includes GRL
         side_join()
-        buckets.reduce_stage("sex_classifier")
+        if need_stage["sex_classifier"]:
+            buckets.reduce_stage("sex_classifier")
+        if not run_decoder:                       # classifier-only step: nothing below needs a gradient
+            buckets.join()
+            ctx.S = None
+            grads = tuple(G[k] if need[k] else None for k in names)
+            G.clear()
+            buckets.views.clear()
+            return (None, None, None) + grads
 
         # ======================= decoder =======================
         g_rec = d_recon.reshape(B, Ltot).contiguous().float()
@@ -559,7 +612,15 @@ class _ConvAEFn(torch.autograd.Function):
         bias_from(st, "decoder.0.bias", 128)
         conv_wgrad("decoder.0.weight", y4, g, 128, 128, 1, L4, K5, 1, 2, s1=n4[2], t1=n4[3], swish=True)
         side_join()
-        buckets.reduce_stage("decoder")
+        if need_stage["decoder"]:
+            buckets.reduce_stage("decoder")
+        if not run_encoder:
+            buckets.join()
+            ctx.S = None
+            grads = tuple(G[k] if need[k] else None for k in names)
+            G.clear()
+            buckets.views.clear()
+            return (None, None, None) + grads
 
         # ======================= encoder =======================
         # d z4 = (decoder.0 dgrad + classifier branch) * swish'(z4), fused into the dgrad launch
@@ -588,7 +649,8 @@ class _ConvAEFn(torch.autograd.Function):
         if ctx.need_input_grad:
             d_feats = ops.convCto1(g, P["encoder.0.weight"], None, flip=True).view(B, T, 80)
         side_join()
-        buckets.reduce_stage("encoder")
+        if need_stage["encoder"]:
+            buckets.reduce_stage("encoder")
         buckets.join()
         ctx.S = None
         grads = tuple(G[k] if need[k] else None for k in names)

@@ -274,12 +274,16 @@ extern "C" int sa_fin_in_fwd(const double* sums, int B, int C, int n, const floa
 // channel; updates running_mean / running_var (unbiased) with `momentum` like nn.BatchNorm1d.
 // sums may come as R partial rows [R][C][2] (the per-utterance level of the slab reduction): they
 // are added here in row order, which saves a launch per BatchNorm
+// count_dev != null: the element count is read on the device (the all-reduced count of a
+// SyncBatchNorm whose ranks hold ragged batches) and `count` is ignored.
 __global__ void sa_fin_bn_fwd_kernel(const double* __restrict__ sums, int R, int C, double count,
                                      const float* __restrict__ gamma, const float* __restrict__ beta,
                                      float eps, float momentum, float* run_mean, float* run_var,
-                                     float* mean, float* rstd, float* scale, float* shift) {
+                                     float* mean, float* rstd, float* scale, float* shift,
+                                     const double* __restrict__ count_dev) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= C) return;
+  if (count_dev) count = *count_dev;
   double S = 0.0, Q = 0.0;
 #pragma unroll 8
   for (int r = 0; r < R; ++r) { S += sums[2 * ((size_t)r * C + i)]; Q += sums[2 * ((size_t)r * C + i) + 1]; }
@@ -299,11 +303,11 @@ __global__ void sa_fin_bn_fwd_kernel(const double* __restrict__ sums, int R, int
 extern "C" int sa_fin_bn_fwd(const double* sums, int R, int C, double count, const float* gamma,
                              const float* beta, float eps, float momentum, float* run_mean,
                              float* run_var, float* mean, float* rstd, float* scale, float* shift,
-                             void* stream) {
-  if (!sums || !gamma || !beta || !mean || !rstd || !scale || !shift || count <= 0 || R < 1) return -22;
+                             const double* count_dev, void* stream) {
+  if (!sums || !gamma || !beta || !mean || !rstd || !scale || !shift || (!count_dev && count <= 0) || R < 1) return -22;
   hipLaunchKernelGGL(sa_fin_bn_fwd_kernel, dim3(sa_div_up(C, 128)), dim3(128), 0,
                      reinterpret_cast<hipStream_t>(stream), sums, R, C, count, gamma, beta, eps,
-                     momentum, run_mean, run_var, mean, rstd, scale, shift);
+                     momentum, run_mean, run_var, mean, rstd, scale, shift, count_dev);
   hipError_t e = hipGetLastError();
   return e == hipSuccess ? 0 : -(int)e;
 }
@@ -338,7 +342,9 @@ __global__ void sa_fin_norm_bwd_kernel(const double* __restrict__ sums, const do
                                        int R, int G, int C, double n, const float* __restrict__ gamma,
                                        const float* __restrict__ mean, const float* __restrict__ rstd,
                                        float sign, float* c1, float* c2, float* c3, float* dgamma,
-                                       float* dbeta, int nb, int coef_blocks) {
+                                       float* dbeta, int nb, int coef_blocks,
+                                       const double* __restrict__ n_dev) {
+  if (n_dev) n = *n_dev;                                // device-side (all-reduced) element count
   if ((int)blockIdx.x < coef_blocks) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < G) {
@@ -380,14 +386,14 @@ __global__ void sa_fin_norm_bwd_kernel(const double* __restrict__ sums, const do
 extern "C" int sa_fin_norm_bwd(const double* sums, const double* lsums, int R, int groups, int C, double n,
                                const float* gamma, const float* mean, const float* rstd, float sign,
                                float* c1, float* c2, float* c3, float* dgamma, float* dbeta,
-                               void* stream) {
+                               const double* n_dev, void* stream) {
   if (!sums || !gamma || !mean || !rstd || !c1 || !c2 || !c3 || groups % C || R < 1) return -22;
   if ((dgamma == nullptr) != (dbeta == nullptr)) return -22;
   const int coef_blocks = sa_div_up(groups, 256);
   const int grid = coef_blocks + (dgamma ? sa_div_up(C, 32) : 0);
   hipLaunchKernelGGL(sa_fin_norm_bwd_kernel, dim3(grid), dim3(256), 0,
                      reinterpret_cast<hipStream_t>(stream), sums, lsums ? lsums : sums, R, groups, C,
-                     n, gamma, mean, rstd, sign, c1, c2, c3, dgamma, dbeta, groups / C, coef_blocks);
+                     n, gamma, mean, rstd, sign, c1, c2, c3, dgamma, dbeta, groups / C, coef_blocks, n_dev);
   hipError_t e = hipGetLastError();
   return e == hipSuccess ? 0 : -(int)e;
 }

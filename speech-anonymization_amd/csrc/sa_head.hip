@@ -345,9 +345,10 @@ __global__ void sa_bn2d_bwd_kernel(const float* __restrict__ G, const float* __r
                                    const double* __restrict__ sums, double count,
                                    const float* __restrict__ gamma, const float* __restrict__ mean,
                                    const float* __restrict__ rstd, int relu_mask, int M, int N,
-                                   float* dH) {
+                                   float* dH, const double* __restrict__ count_dev) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= M * N) return;
+  if (count_dev) count = *count_dev;                    // device-side (all-reduced) row count
   const int n = i % N;
   const float hh = (H[i] - mean[n]) * rstd[n];
   float v = gamma[n] * rstd[n] * (G[i] - (float)(sums[2 * n] / count) - hh * (float)(sums[2 * n + 1] / count));
@@ -357,11 +358,11 @@ __global__ void sa_bn2d_bwd_kernel(const float* __restrict__ G, const float* __r
 
 extern "C" int sa_bn2d_bwd(const float* G, const float* H, const double* sums, double count,
                            const float* gamma, const float* mean, const float* rstd, int relu_mask,
-                           int M, int N, float* dH, void* stream) {
+                           int M, int N, float* dH, const double* count_dev, void* stream) {
   if (!G || !H || !sums || !gamma || !mean || !rstd || !dH) return -22;
   hipLaunchKernelGGL(sa_bn2d_bwd_kernel, dim3(sa_div_up(M * N, 256)), dim3(256), 0,
                      reinterpret_cast<hipStream_t>(stream), G, H, sums, count, gamma, mean, rstd,
-                     relu_mask, M, N, dH);
+                     relu_mask, M, N, dH, count_dev);
   hipError_t e = hipGetLastError();
   return e == hipSuccess ? 0 : -(int)e;
 }

@@ -48,13 +48,24 @@ class CsvDataset:
         return len(self.items)
 
 
-def batches(dataset, batch_size, shuffle=False, seed=0, rank=0, world=1):
-    """yields Batch objects; utterances are sharded by index across data-parallel ranks."""
-    idx = list(range(len(dataset)))
+def shard_indices(n_items, shuffle=False, seed=0, epoch=0, rank=0, world=1):
+    """Index list of one rank for one epoch, torch DistributedSampler semantics: the (optionally
+    shuffled, seed + epoch like speechbrain's ReproducibleRandomSampler) list is padded by
+    wrapping around to a multiple of `world`, then dealt round-robin -- every rank gets the SAME
+    number of items, hence the same number of batches (a rank with one batch more would wait
+    forever in the SyncBatchNorm / gradient all-reduce of a step its peers never run)."""
+    idx = list(range(n_items))
     if shuffle:
-        rs = np.random.RandomState(seed)
-        rs.shuffle(idx)
-    idx = idx[rank::world]
+        np.random.RandomState(seed + epoch).shuffle(idx)
+    if world > 1 and idx:
+        total = -(-len(idx) // world) * world
+        idx = (idx * (total // len(idx) + 1))[:total]
+    return idx[rank::world]
+
+
+def batches(dataset, batch_size, shuffle=False, seed=0, rank=0, world=1, epoch=0):
+    """yields Batch objects; utterances are sharded by index across data-parallel ranks."""
+    idx = shard_indices(len(dataset), shuffle, seed, epoch, rank, world)
     for i in range(0, len(idx), batch_size):
         rows = [dataset.items[j] for j in idx[i:i + batch_size]]
         sigs = [read_audio(r["wav"]) for r in rows]

@@ -94,20 +94,33 @@ class StageBuckets:
     def view(self, key):
         return self.views[key]
 
+    @staticmethod
+    def _average(flat, w):
+        """one collective: RCCL averages in the reduction itself (ncclAvg); gloo has no AVG"""
+        if dist.get_backend() == "nccl":
+            dist.all_reduce(flat, op=dist.ReduceOp.AVG)
+        else:
+            dist.all_reduce(flat)
+            flat.div_(w)
+
     def reduce_stage(self, stage):
-        """average bucket `stage` across ranks, asynchronously on the side stream."""
+        """average bucket `stage` across ranks, asynchronously on the side stream.  The buckets
+        are allocated per backward on purpose: autograd adopts their views as .grad, and with
+        gradient accumulation the previous micro-step's .grad must stay intact while this one is
+        written (a persistent bucket would be overwritten under it)."""
         w = world_size()
         if w == 1:
             return
         flat = self.flat[stage]
-        if self.side is None:                      # CPU / gloo (tests)
-            dist.all_reduce(flat)
-            flat.div_(w)
+        if self.side is None or not flat.is_cuda:  # CPU / gloo (tests)
+            self._average(flat, w)
             return
         self.side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(self.side):
-            dist.all_reduce(flat)
-            flat.div_(w)
+            self._average(flat, w)
+        # allocated on the main stream, used on the side stream: the caching allocator must not
+        # hand the block out again before the collective has finished with it
+        flat.record_stream(self.side)
         self.pending = True
 
     def join(self):

@@ -40,10 +40,10 @@ class _Profile:
     recorded on the stream the kernel is launched on = torch's current stream)."""
 
     def __init__(self):
-        self.key, self.ev, self.bytes, self.flops = None, [], 0, 0
+        self.key, self.ev, self.bytes, self.alg_bytes, self.flops = None, [], 0, 0, 0
 
     def enable(self, key):
-        self.key, self.ev, self.bytes, self.flops = key, [], 0, 0
+        self.key, self.ev, self.bytes, self.alg_bytes, self.flops = key, [], 0, 0, 0
 
     def start(self, key):
         if key != self.key:
@@ -52,18 +52,21 @@ class _Profile:
         e.record()
         return e
 
-    def stop(self, e0, nbytes, flops):
+    def stop(self, e0, nbytes, flops, alg_bytes=None):
+        """nbytes: what the launch is designed to move; alg_bytes: SURVEY 8(d)'s algorithmic
+        figure (inputs + outputs once, + the stored tensor a fused backward epilogue re-reads)."""
         e1 = torch.cuda.Event(enable_timing=True)
         e1.record()
         self.ev.append((e0, e1))
         self.bytes += nbytes
+        self.alg_bytes += nbytes if alg_bytes is None else alg_bytes
         self.flops += flops
 
     def collect(self):
         torch.cuda.synchronize()
         ms = sum(a.elapsed_time(b) for a, b in self.ev)
         out = {"kernel": self.key, "launches": len(self.ev), "ms": ms, "bytes": self.bytes,
-               "flops": self.flops}
+               "alg_bytes": self.alg_bytes, "flops": self.flops}
         self.key, self.ev = None, []
         return out
 
@@ -200,8 +203,10 @@ def conv_gemm(x, wp, bias, cin, cout, sa, u, phases, Lout, s1=None, t1=None, s2=
             extra += y.numel() * esz * (2 if ep.get("g2") is not None else 1)   # stored forward tensor (+ 2nd gradient) read
         if nb:
             extra += x.numel() * esz                                             # stored forward tensor of the layer above
-        PROFILE.stop(e0, (x.numel() + y.numel()) * esz + ntap * cin * cout * esz + extra,
-                     2 * B * (-(-Lout // u)) * ntap * cin * cout)
+        io = (x.numel() + y.numel()) * esz
+        PROFILE.stop(e0, io + ntap * cin * cout * esz + extra,
+                     2 * B * (-(-Lout // u)) * ntap * cin * cout,
+                     alg_bytes=io + (y.numel() * esz if ep else 0))
     out_t = (y, stats) if want_stats else (y,)
     if nb and nb.get("want_colsum"):
         out_t = out_t + (colsum,)
@@ -324,12 +329,14 @@ def fin_in_fwd(sums, B, Cc, n, gamma, beta, eps=1e-5):
     return o[0], o[1], o[2], o[3]          # mean, rstd, scale, shift
 
 
-def fin_bn_fwd(sums, Cc, count, gamma, beta, run_mean=None, run_var=None, eps=1e-5, momentum=0.1):
+def fin_bn_fwd(sums, Cc, count, gamma, beta, run_mean=None, run_var=None, eps=1e-5, momentum=0.1,
+               count_dev=None):
+    """count_dev: fp64 device scalar holding the (all-reduced) element count; overrides count."""
     lib = L.load()
     o = torch.empty(4, Cc, dtype=torch.float32, device=sums.device)
     L.check(lib.sa_fin_bn_fwd(_f(sums), sums.numel() // (2 * Cc), Cc, C.c_double(count), _f(gamma), _f(beta), C.c_float(eps),
                               C.c_float(momentum), _f(run_mean), _f(run_var), _f(o[0]), _f(o[1]),
-                              _f(o[2]), _f(o[3]), L.stream()), "sa_fin_bn_fwd")
+                              _f(o[2]), _f(o[3]), _f(count_dev), L.stream()), "sa_fin_bn_fwd")
     return o[0], o[1], o[2], o[3]
 
 
@@ -341,14 +348,15 @@ def fin_bn_eval(Cc, gamma, beta, run_mean, run_var, eps=1e-5):
     return o[0], o[1], o[2], o[3]
 
 
-def fin_norm_bwd(sums, lsums, groups, Cc, n, gamma, mean, rstd, sign=1.0, dgamma=None, dbeta=None):
+def fin_norm_bwd(sums, lsums, groups, Cc, n, gamma, mean, rstd, sign=1.0, dgamma=None, dbeta=None,
+                 n_dev=None):
     lib = L.load()
     o = torch.empty(3, groups, dtype=torch.float32, device=sums.device)
     R = sums.numel() // (2 * groups)
     assert lsums is None or lsums.numel() == sums.numel()
     L.check(lib.sa_fin_norm_bwd(_f(sums), _f(lsums), R, groups, Cc, C.c_double(n), _f(gamma), _f(mean),
                                 _f(rstd), C.c_float(sign), _f(o[0]), _f(o[1]), _f(o[2]), _f(dgamma),
-                                _f(dbeta), L.stream()), "sa_fin_norm_bwd")
+                                _f(dbeta), _f(n_dev), L.stream()), "sa_fin_norm_bwd")
     return o[0], o[1], o[2]
 
 
@@ -437,12 +445,12 @@ def colsums(X, H=None, hmean=None, hrstd=None):
     return s
 
 
-def bn2d_bwd(G, H, sums, count, gamma, mean, rstd, relu_mask):
+def bn2d_bwd(G, H, sums, count, gamma, mean, rstd, relu_mask, count_dev=None):
     lib = L.load()
     M, N = G.shape
     dH = torch.empty_like(G)
     L.check(lib.sa_bn2d_bwd(_f(G), _f(H), _f(sums), C.c_double(count), _f(gamma), _f(mean), _f(rstd),
-                            int(relu_mask), M, N, _f(dH), L.stream()), "sa_bn2d_bwd")
+                            int(relu_mask), M, N, _f(dH), _f(count_dev), L.stream()), "sa_bn2d_bwd")
     return dH
 
 

@@ -52,15 +52,21 @@ def main(argv):
         tr = data.CsvDataset(hparams["train_csv"], rep, hparams.get("sorting", "random"))
         va = data.CsvDataset(hparams["valid_csv"], rep, "ascending")
         shuffle = hparams["train_dataloader_opts"].get("shuffle", False) and hparams.get("sorting") == "random"
-        train = lambda: data.batches(tr, bs, shuffle, hparams["seed"], rank, world)
-        valid = lambda: data.batches(va, bs, False, 0, rank, world)
+        train = lambda epoch: data.batches(tr, bs, shuffle, hparams["seed"], rank, world, epoch)
+        valid = lambda epoch: data.batches(va, bs, False, 0, rank, world)
+    if synthetic:
+        train_, valid_ = train, valid
+        train, valid = (lambda epoch: train_()), (lambda epoch: valid_())
 
     class Loader:
+        """re-iterable; the epoch number seeds the shuffle (seed + epoch)"""
+
         def __init__(self, f):
-            self.f = f
+            self.f, self.epoch = f, 0
 
         def __iter__(self):
-            return iter(self.f())
+            self.epoch += 1
+            return iter(self.f(self.epoch))
 
     sa_brain.fit(hparams["epoch_counter"], Loader(train), Loader(valid))
     if sdist.world_size() > 1:

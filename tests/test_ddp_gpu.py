@@ -21,18 +21,26 @@ def _inputs(B, T):
     return feats, target, torch.arange(B) % 2
 
 
-def _run(model, feats, target, gender):
+def _run(model, feats, target, gender, parts=None):
+    """parts: [(lo, hi), ...] = the per-rank shards a data-parallel run would use; the loss is then
+    the MEAN OVER RANKS of the per-rank mean losses (what averaging the ranks' gradients computes;
+    equal to the plain batch mean only for equal shards)."""
     from speech_anonymization_amd import ops
     recon, logp = model(feats.cuda())
-    loss_r, g_r = ops.recon_loss(recon.detach().contiguous(), target.cuda().contiguous(), "l1")
-    out, dn, _ = ops.cls_losses(logp.detach(), gender.cuda())
-    torch.autograd.backward([recon, logp], [0.1 * g_r.view_as(recon), 0.9 * dn])
+    parts = parts or [(0, feats.shape[0])]
+    grs, dns = [], []
+    for lo, hi in parts:
+        _, g_r = ops.recon_loss(recon.detach()[lo:hi].contiguous(), target[lo:hi].cuda().contiguous(), "l1")
+        _, dn, _ = ops.cls_losses(logp.detach()[lo:hi].contiguous(), gender[lo:hi].cuda())
+        grs.append(g_r.view(hi - lo, *recon.shape[1:]) / len(parts))
+        dns.append(dn / len(parts))
+    torch.autograd.backward([recon, logp], [0.1 * torch.cat(grs), 0.9 * torch.cat(dns)])
     torch.cuda.synchronize()
     return {k: p.grad.detach().cpu() for k, p in model.named_parameters()}, \
            {k: v.detach().cpu() for k, v in model.state_dict().items() if "running" in k}
 
 
-def _worker(rank, world, port, q):
+def _worker(rank, world, port, q, cuts=(0, 3, 6)):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
                       LOCAL_RANK=str(rank), SA_DIST_BACKEND="gloo", SA_SAME_DEVICE="1")
     sys.path.insert(0, ROOT)
@@ -45,21 +53,24 @@ def _worker(rank, world, port, q):
     m.load_state_dict(numpy_params(8886))
     m.cuda().train()
     feats, target, gender = _inputs(6, 72)
-    lo, hi = sdist.shard_batch(6, rank, world)
+    lo, hi = cuts[rank], cuts[rank + 1]
     grads, bufs = _run(m, feats[lo:hi], target[lo:hi], gender[lo:hi])
     q.put((rank, {k: v.numpy() for k, v in grads.items()}, {k: v.numpy() for k, v in bufs.items()}))
     torch.distributed.barrier()
     torch.distributed.destroy_process_group()
 
 
-def test_two_ranks_equal_one_rank_with_double_batch():
+@pytest.mark.parametrize("cuts", [(0, 3, 6), (0, 4, 6)], ids=["3+3", "4+2"])
+def test_two_ranks_equal_one_rank_with_double_batch(cuts):
+    """equal shards (3 + 3) and ragged ones (4 + 2: the SyncBatchNorm element COUNTS differ per
+    rank and are all-reduced beside the sums, like torch.nn.SyncBatchNorm)"""
     import torch.multiprocessing as mp
     from oracle.convae import numpy_params
     from speech_anonymization_amd.convae import ConvAutoencoder
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    port = 29600 + (os.getpid() % 1000)
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    port = 29600 + (os.getpid() % 1000) + cuts[1]
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q, cuts)) for r in range(2)]
     for p in procs:
         p.start()
     res = sorted([q.get(timeout=300) for _ in procs], key=lambda r: r[0])
@@ -70,7 +81,7 @@ def test_two_ranks_equal_one_rank_with_double_batch():
     m.load_state_dict(numpy_params(8886))
     m.cuda().train()
     feats, target, gender = _inputs(6, 72)
-    ref, ref_bufs = _run(m, feats, target, gender)
+    ref, ref_bufs = _run(m, feats, target, gender, parts=[(cuts[0], cuts[1]), (cuts[1], cuts[2])])
 
     def rel(a, b):
         a, b = torch.as_tensor(a).double(), b.double()

@@ -72,7 +72,8 @@ def test_csv_manifest_wav_and_batches(tmp_path):
     assert float(wav[0, 3200:].abs().max()) == 0.0 and bs[0].gender.tolist() == [1, 0]
     shard0 = list(data.batches(ds, 2, rank=0, world=2))
     shard1 = list(data.batches(ds, 2, rank=1, world=2))
-    assert sum(b.gender.numel() for b in shard0 + shard1) == 3
+    # DistributedSampler semantics: 3 utterances over 2 ranks -> 2 each (one wraps around)
+    assert [sum(b.gender.numel() for b in sh) for sh in (shard0, shard1)] == [2, 2]
 
 
 def test_checkpoint_layout_roundtrip(tmp_path):
@@ -115,8 +116,11 @@ def _dist_worker(rank, world, port, q):
     sizes = {st: b.flat[st].numel() for st in b.STAGES}
     sums = torch.tensor([[1.0 + rank, 2.0], [3.0, 4.0 * (rank + 1)]], dtype=torch.float64)
     wf = model._bn_allreduce(sums)
+    # ragged ranks: rank 0 holds B=3 utterances of L4=500 rows, rank 1 B=2 of 700
+    Bq, L4 = (3, 500) if rank == 0 else (2, 700)
+    gc = model._bn_global_counts([Bq * L4, Bq * (L4 - 4), Bq], torch.device("cpu"))
     lo, hi = sdist.shard_batch(10, rank, world)
-    q.put((rank, ok, sizes, wf, sums.tolist(), (lo, hi), sdist.if_main_process()))
+    q.put((rank, ok, sizes, wf, sums.tolist(), (lo, hi), sdist.if_main_process(), gc.tolist()))
     torch.distributed.barrier()
     torch.distributed.destroy_process_group()
 
@@ -134,8 +138,9 @@ def test_data_parallel_plumbing_gloo_world2():
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
-    for rank, ok, sizes, wf, sums, shard, main in res:
+    for rank, ok, sizes, wf, sums, shard, main, gc in res:
         assert ok and wf == 2 and main == (rank == 0)
+        assert gc == [3 * 500 + 2 * 700, 3 * 496 + 2 * 696, 5]          # element counts add up across ranks
         assert sizes == {"decoder": 154561, "sex_classifier": 223298, "encoder": 155264}
         assert sums == [[3.0, 4.0], [6.0, 12.0]]
     assert res[0][5] == (0, 5) and res[1][5] == (5, 10)
@@ -151,3 +156,83 @@ def test_syncbn_sum_combination_equals_full_batch_statistics():
     n = 8 * 50
     mean, var = s / n, q / n - (s / n) ** 2
     assert torch.allclose(mean, x.mean(dim=(0, 2))) and torch.allclose(var, x.var(dim=(0, 2), unbiased=False))
+
+
+def test_shard_indices_give_every_rank_the_same_number_of_batches():
+    """DistributedSampler semantics (a rank with an extra batch would hang in the collectives of a
+    step its peers never run) and a seed + epoch shuffle like ReproducibleRandomSampler."""
+    from speech_anonymization_amd.data import shard_indices
+    for n, world, bs in [(11, 2, 5), (7, 4, 2), (16, 8, 1), (3, 8, 2), (10, 1, 4)]:
+        shards = [shard_indices(n, True, 8886, 1, r, world) for r in range(world)]
+        assert len({len(s) for s in shards}) == 1, (n, world)
+        assert len({-(-len(s) // bs) for s in shards}) == 1
+        assert set(i for s in shards for i in s) == set(range(n))             # nothing dropped
+        assert sum(len(s) for s in shards) == -(-n // world) * world
+    a, b = shard_indices(20, True, 8886, 1, 0, 1), shard_indices(20, True, 8886, 2, 0, 1)
+    assert a != b and sorted(a) == sorted(b) == list(range(20))              # reshuffled every epoch
+    assert shard_indices(20, True, 8886, 1, 0, 1) == a                        # reproducibly
+
+
+def test_checkpoint_names_are_unique_and_resume_restores_optimizer(tmp_path):
+    """two saves within one second get +00 / +01 (speechbrain's suffix) instead of sharing a
+    directory; Brain.on_fit_start resumes model, scheduler, counter, optimizer moments and step
+    from the newest checkpoint (a rerun on an existing output folder continues, it does not restart)."""
+    from speech_anonymization_amd.brain import Brain, EpochCounter, NoamScheduler
+    from speech_anonymization_amd.checkpoint import Checkpointer
+    import functools
+
+    def make():
+        torch.manual_seed(0)
+        lin = torch.nn.Linear(4, 3)
+        noam, counter = NoamScheduler(1.0, 25000, 768), EpochCounter(10)
+        ck = Checkpointer(str(tmp_path / "save"), {"model": lin, "noam_scheduler": noam, "counter": counter})
+        br = Brain(modules={"lin": lin}, opt_class=functools.partial(torch.optim.Adam, lr=1e-2),
+                   run_opts={"device": "cpu"}, checkpointer=ck)
+        return br, lin, noam, counter, ck
+
+    br, lin, noam, counter, ck = make()
+    br.on_fit_start()
+    assert br.resumed_from is None
+    for _ in range(3):
+        lin(torch.ones(2, 4)).sum().backward()
+        br.optimizer.step(); br.optimizer.zero_grad(); noam(br.optimizer)
+    counter.current, br.step, br.avg_train_loss = 2, 3, 0.25
+    p1 = ck.save(br, epoch=2, meta={"loss": 0.25})
+    p2 = ck.save(br, epoch=2, meta={"loss": 0.25})
+    assert p1 != p2 and os.path.isdir(p1) and os.path.isdir(p2)
+    assert {os.path.basename(p1)[-3:], os.path.basename(p2)[-3:]} <= {"+00", "+01"}
+    assert "optimizer.ckpt" in os.listdir(p2) and "brain.ckpt" in os.listdir(p2)
+    want_w = lin.weight.detach().clone()
+    want_m = br.optimizer.state[lin.weight]["exp_avg"].clone()
+
+    br2, lin2, noam2, counter2, _ = make()
+    assert not torch.equal(lin2.weight, want_w)
+    br2.on_fit_start()
+    assert br2.resumed_from == p2
+    assert torch.equal(lin2.weight, want_w) and noam2.n_steps == 3 and counter2.current == 2
+    assert torch.equal(br2.optimizer.state[lin2.weight]["exp_avg"], want_m)
+    assert br2.step == 3 and abs(br2.avg_train_loss - 0.25) < 1e-12
+
+
+def test_bench_launches_its_own_ranks():
+    """`python bench.py --gpus 2` without a torchrun environment starts its two ranks itself (before
+    anything touches a GPU), they rendezvous (gloo here), take the MAX over ranks and rank 0's JSON
+    line is relayed: what the driver's plain `python3 bench.py --gpus 8` relies on."""
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3",
+                          "--plumbing-only"], capture_output=True, text=True, timeout=300, env=env)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    rec = json.loads(lines[0])
+    assert rec["n_gpus"] == 2 and rec["ranks_seen"] == 2 and rec["backend"] == "gloo"
+    assert rec["plumbing_only"] is True and rec["value"] is None
+    assert rec["ms_per_step"] >= 20.0            # rank 1 sleeps 2 x 10 ms per step: MAX over ranks, not rank 0's 10
+
+
+def test_train_logger_number_format():
+    """speechbrain's FileTrainLogger: '%.2f' only for 1 < v < 100 (no abs: the negative losses of
+    the endtoend sign branch print in scientific notation, as in the reference's train_log.txt)"""
+    from speech_anonymization_amd.brain import FileTrainLogger
+    assert FileTrainLogger._fmt({"a": 2.5, "b": -2.5, "c": 0.5, "d": 150.0}) == "a: 2.50, b: -2.50e+00, c: 5.00e-01, d: 1.50e+02"

@@ -10,6 +10,7 @@ import torch.nn.functional as F
 pytestmark = pytest.mark.gpu
 
 DT = [torch.float32, torch.bfloat16]
+DTX = DT + ["bf16x3"]            # + the benchmarked precision: fp32 storage, split-bf16 MFMA operands
 
 
 def dev():
@@ -22,18 +23,30 @@ def rel_mse(a, b):
 
 
 def tol(dt):
-    return 1e-10 if dt == torch.float32 else 2e-5
+    # bf16x3: ~16 mantissa bits per operand (hi + lo) -> products good to ~2^-16 each
+    return 1e-10 if dt == torch.float32 else (2e-9 if dt == "bf16x3" else 2e-5)
+
+
+def sdt(dt):
+    """storage dtype of a precision"""
+    return torch.float32 if dt == "bf16x3" else dt
+
+
+def kcode(dt):
+    """(kernel code of conv_gemm, kernel code of wgrad) or (None, None) = from the storage dtype"""
+    from speech_anonymization_amd import _lib as L
+    return (L.BF16X3, L.BF16X1F) if dt == "bf16x3" else (None, None)
 
 
 def rnd(dt, *shape, seed=0, scale=1.0):
     g = torch.Generator().manual_seed(seed)
     x = torch.randn(*shape, generator=g) * scale
-    return x.to(dt).float()          # values exactly representable in dt
+    return x.to(sdt(dt)).float()     # values exactly representable in the storage dtype
 
 
 def cl(x_bcl, dt):
     """[B,C,L] cpu fp32 -> channels-last [B,L,C] device tensor of dtype dt."""
-    return x_bcl.permute(0, 2, 1).contiguous().to(dev(), dt)
+    return x_bcl.permute(0, 2, 1).contiguous().to(dev(), sdt(dt))
 
 
 def uncl(y_blc):
@@ -56,12 +69,10 @@ def ref_fwd(x, w, b, stride, dil, pad, transposed):
     return F.conv1d(x, w, b, stride=stride, padding=pad, dilation=dil)
 
 
-@pytest.mark.parametrize("dt", DT)
-@pytest.mark.parametrize("layer", LAYERS, ids=[l[0] for l in LAYERS])
-def test_conv_fwd_dgrad_wgrad(layer, dt):
+def _conv_case(layer, dt, B, Lin):
     from speech_anonymization_amd import ops
     name, cin, cout, K, stride, dil, pad, tr = layer
-    B, Lin = 2, 300 if stride == 1 or tr else 300
+    cg, cw = kcode(dt)
     x = rnd(dt, B, cin, Lin, seed=1)
     wshape = (cin, cout, K) if tr else (cout, cin, K)
     w = rnd(dt, *wshape, seed=2, scale=(cin * K) ** -0.5)
@@ -76,64 +87,132 @@ def test_conv_fwd_dgrad_wgrad(layer, dt):
     xd, wd, bd = cl(x.detach(), dt), w.detach().to(dev()), bias.to(dev())
     # ---- forward ----
     if tr:
-        wp = ops.pack_weights(wd, "convT_fwd", dt)
-        yd, st = ops.conv_gemm(xd, wp, bd, cin, cout, 1, 2, ops.UP2, Lout, want_stats=True)
+        wp = ops.pack_weights(wd, "convT_fwd", sdt(dt), cg)
+        yd, st = ops.conv_gemm(xd, wp, bd, cin, cout, 1, 2, ops.UP2, Lout, want_stats=True, code=cg)
     else:
-        wp = ops.pack_weights(wd, "conv_fwd", dt)
+        wp = ops.pack_weights(wd, "conv_fwd", sdt(dt), cg)
         yd, st = ops.conv_gemm(xd, wp, bd, cin, cout, stride, 1, ops.taps_conv(K, dil, pad), Lout,
-                               want_stats=True)
+                               want_stats=True, code=cg)
     torch.cuda.synchronize()
     assert rel_mse(uncl(yd), y.detach()) < tol(dt), name
     # epilogue statistics = sum / sumsq of the stored values per (b, c)
-    s = st.sum(dim=1).cpu()
-    yy = yd.float().cpu()
-    assert torch.allclose(s[..., 0], yy.sum(dim=1), rtol=1e-4, atol=1e-3)
-    assert torch.allclose(s[..., 1], (yy * yy).sum(dim=1), rtol=1e-4, atol=1e-3)
+    s = ops.sum_partials(st, B).view(B, cout, 2).cpu()
+    yy = yd.double().cpu()
+    assert torch.allclose(s[..., 0], yy.sum(dim=1), rtol=1e-4, atol=1e-3 * (Lout / 300) ** 0.5)
+    assert torch.allclose(s[..., 1], (yy * yy).sum(dim=1), rtol=1e-4, atol=1e-3 * (Lout / 300) ** 0.5)
     # ---- dgrad ----
     gyd = cl(gy, dt)
     if tr:
-        wpd = ops.pack_weights(wd, "convT_dgrad", dt)
-        gxd = ops.conv_gemm(gyd, wpd, None, cout, cin, 2, 1, ops.taps_convT_dgrad(), Lin)
+        wpd = ops.pack_weights(wd, "convT_dgrad", sdt(dt), cg)
+        gxd = ops.conv_gemm(gyd, wpd, None, cout, cin, 2, 1, ops.taps_convT_dgrad(), Lin, code=cg)
     elif stride == 2:
-        wpd = ops.pack_weights(wd, "conv_dgrad", dt)
-        gxd = ops.conv_gemm(gyd, wpd, None, cout, cin, 1, 2, ops.UP2, Lin)
+        wpd = ops.pack_weights(wd, "conv_dgrad", sdt(dt), cg)
+        gxd = ops.conv_gemm(gyd, wpd, None, cout, cin, 1, 2, ops.UP2, Lin, code=cg)
     else:
-        wpd = ops.pack_weights(wd, "conv_dgrad", dt)
-        gxd = ops.conv_gemm(gyd, wpd, None, cout, cin, 1, 1, ops.taps_conv_dgrad_s1(K, dil, pad), Lin)
+        wpd = ops.pack_weights(wd, "conv_dgrad", sdt(dt), cg)
+        gxd = ops.conv_gemm(gyd, wpd, None, cout, cin, 1, 1, ops.taps_conv_dgrad_s1(K, dil, pad), Lin,
+                            code=cg)
     torch.cuda.synchronize()
     assert rel_mse(uncl(gxd), gx) < tol(dt), name + " dgrad"
-    # ---- wgrad ----
+    # ---- wgrad (bf16x3 models run it with single-rounded bf16 operands, SA_BF16X1F: a weight
+    # gradient averages ~B*L independent roundings of relative size 2^-9) ----
     gwd = torch.zeros(wshape, device=dev())
     if tr:
         taps = [(1, 0), (1, 1), (0, 0), (0, 1), (-1, 0)]
-        ops.wgrad(xd, gyd, cin, cout, 1, 2, taps, Lin, gwd, (cout * K, K, 1))
+        ops.wgrad(xd, gyd, cin, cout, 1, 2, taps, Lin, gwd, (cout * K, K, 1), code=cw)
     else:
         taps = [(k * dil - pad, 0) for k in range(K)]
-        ops.wgrad(xd, gyd, cin, cout, stride, 1, taps, Lout, gwd, (K, cin * K, 1))
+        ops.wgrad(xd, gyd, cin, cout, stride, 1, taps, Lout, gwd, (K, cin * K, 1), code=cw)
     torch.cuda.synchronize()
-    assert rel_mse(gwd, gw) < tol(dt), name + " wgrad"
+    assert rel_mse(gwd, gw) < (2e-5 if dt == "bf16x3" else tol(dt)), name + " wgrad"
 
 
-@pytest.mark.parametrize("dt", DT)
+@pytest.mark.parametrize("dt", DTX, ids=["f32", "bf16", "bf16x3"])
+@pytest.mark.parametrize("layer", LAYERS, ids=[l[0] for l in LAYERS])
+def test_conv_fwd_dgrad_wgrad(layer, dt):
+    _conv_case(layer, dt, 2, 300)
+
+
+@pytest.mark.parametrize("dt", ["bf16x3", torch.float32], ids=["bf16x3", "f32"])
+@pytest.mark.parametrize("layer", LAYERS, ids=[l[0] for l in LAYERS])
+def test_conv_fwd_dgrad_wgrad_at_training_length(layer, dt):
+    """every template at the row counts of the benchmark shape (T = 1008: 80 640 / 40 320 /
+    20 160 rows per utterance -> 158-630 tiles, multi-chunk split-K weight gradients, two-level
+    slab sums) against F.conv1d / F.conv_transpose1d on the CPU."""
+    name, cin, cout, K, stride, dil, pad, tr = layer
+    Lin = {32: 80640, 64: 40320, 128: 20160}[cin]
+    _conv_case(layer, dt, 2, Lin)
+
+
+@pytest.mark.parametrize("dt", DTX, ids=["f32", "bf16", "bf16x3"])
 def test_conv_prologue_relu(dt):
     """IN affine + swish + BN affine in the prologue, zero padding applied AFTER the transform,
     ReLU epilogue; ragged length (not a multiple of the 128-row tile)."""
     from speech_anonymization_amd import ops
     B, Cc, Lin, K = 3, 128, 517, 5
+    cg, _ = kcode(dt)
     x = rnd(dt, B, Cc, Lin, seed=5)
     w = rnd(dt, Cc, Cc, K, seed=6, scale=(Cc * K) ** -0.5)
     s1, t1 = 1 + 0.2 * rnd(torch.float32, B, Cc, seed=7), 0.3 * rnd(torch.float32, B, Cc, seed=8)
     s2, t2 = 1 + 0.2 * rnd(torch.float32, Cc, seed=9), 0.3 * rnd(torch.float32, Cc, seed=10)
     z = x * s1[:, :, None] + t1[:, :, None]
     a = (z * torch.sigmoid(z)) * s2[None, :, None] + t2[None, :, None]
-    a = a.to(dt).float()                                   # the kernel stages the operand in dt
+    a = a.to(sdt(dt)).float()                              # the kernel stages the operand in dt
     y = F.relu(F.conv1d(a, w, None, padding=2))
-    wp = ops.pack_weights(w.to(dev()), "conv_fwd", dt)
+    wp = ops.pack_weights(w.to(dev()), "conv_fwd", sdt(dt), cg)
     yd = ops.conv_gemm(cl(x, dt), wp, None, Cc, Cc, 1, 1, ops.taps_conv(K, 1, 2), Lin,
                        s1=s1.to(dev()), t1=t1.to(dev()), s2=s2.to(dev()), t2=t2.to(dev()),
-                       swish=True, relu=True)
+                       swish=True, relu=True, code=cg)
     torch.cuda.synchronize()
-    assert rel_mse(uncl(yd), y) < (1e-9 if dt == torch.float32 else 1e-4)
+    assert rel_mse(uncl(yd), y) < {torch.float32: 1e-9, "bf16x3": 1e-8}.get(dt, 1e-4)
+
+
+@pytest.mark.parametrize("per_c,relu_mask", [(False, False), (True, True)], ids=["instnorm", "batchnorm_relu"])
+@pytest.mark.parametrize("layer", [LAYERS[1], LAYERS[3], LAYERS[6], LAYERS[7]],
+                         ids=["enc5", "enc11", "tdnn6", "dec1"])
+def test_conv_norm_backward_prologue(layer, per_c, relu_mask):
+    """The normalisation-backward prologue of the data-gradient launches (SaConvArgs.nb_*, the
+    PRO2 template, bf16x3): d y = c1*dz + c2*y + c3 [* (y > 0)] formed while the rows are staged,
+    then the data-gradient convolution over d y; by-products: bf16(d y) (the weight gradient's
+    operand) and the column sums of d y (the bias gradient).  Reference: the same arithmetic in
+    torch on the CPU (what sa_ew_apply + a plain data gradient compute)."""
+    from speech_anonymization_amd import _lib as L, ops
+    name, cin, cout, K, stride, dil, pad, tr = layer
+    B, Lx = 3, 517                      # Lx = rows of the layer's INPUT x (the dgrad's output)
+    w = rnd(torch.float32, *((cin, cout, K) if tr else (cout, cin, K)), seed=2, scale=(cin * K) ** -0.5)
+    x = rnd(torch.float32, B, cin, Lx, seed=1).requires_grad_(True)
+    yref = ref_fwd(x, w, None, stride, dil, pad, tr)
+    Ly = yref.shape[2]
+    dz = rnd(torch.float32, B, cout, Ly, seed=3)
+    ystored = rnd(torch.float32, B, cout, Ly, seed=4)          # forward tensor of the layer above
+    shp = (cout,) if per_c else (B, cout)
+    c1, c2, c3 = (1 + 0.2 * rnd(torch.float32, *shp, seed=5), 0.1 * rnd(torch.float32, *shp, seed=6),
+                  0.05 * rnd(torch.float32, *shp, seed=7))
+    bc = (lambda c: c[None, :, None]) if per_c else (lambda c: c[:, :, None])
+    dy = bc(c1) * dz + bc(c2) * ystored + bc(c3)
+    if relu_mask:
+        dy = dy * (ystored > 0)
+    (gx,) = torch.autograd.grad(yref, x, dy)
+    d = dev()
+    if tr:
+        wp = ops.pack_weights(w.to(d), "convT_dgrad", torch.float32, L.BF16X3)
+        args = (cout, cin, 2, 1, ops.taps_convT_dgrad(), Lx)
+    else:
+        wp = ops.pack_weights(w.to(d), "conv_dgrad", torch.float32, L.BF16X3)
+        args = (cout, cin, 1, 1, ops.taps_conv_dgrad_s1(K, dil, pad), Lx)
+    dzd, yd = cl(dz, torch.float32), cl(ystored, torch.float32)
+    dyc = torch.full(dzd.shape, float("nan"), dtype=torch.bfloat16, device=d)
+    out = ops.conv_gemm(dzd, wp, None, *args, code=L.BF16X3, a_out=dyc,
+                        nb=dict(x=yd, c1=c1.to(d).contiguous(), c2=c2.to(d).contiguous(),
+                                c3=c3.to(d).contiguous(), per_c=per_c, relu_mask=relu_mask,
+                                want_colsum=True))
+    gxd, cs = out
+    torch.cuda.synchronize()
+    assert rel_mse(uncl(gxd), gx) < 2e-9
+    dy_cl = dy.permute(0, 2, 1)
+    assert not torch.isnan(dyc.float()).any()
+    assert rel_mse(dyc.float().cpu(), dy_cl.bfloat16().float()) < 1e-6       # one bf16 rounding (ties aside)
+    assert torch.allclose(cs.sum(1).cpu().double(), dy_cl.double().sum(1), rtol=1e-4, atol=2e-3)
 
 
 @pytest.mark.parametrize("dt", DT)

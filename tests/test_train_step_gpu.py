@@ -20,6 +20,36 @@ def test_train_step_bf16_runs_and_tracks_oracle():
     smoke_step.run(torch.bfloat16)
 
 
+@pytest.mark.parametrize("dtype", [torch.float32, "bf16x3"], ids=["f32", "bf16x3"])
+def test_teacher_forced_four_steps(dtype):
+    """steps 2-4 pinned at the step-1 tolerance (loss 3e-5 / 3e-4, every gradient 2e-5 / 1e-4)"""
+    from tests import smoke_step
+    smoke_step.run_teacher_forced(dtype, steps=4)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, "bf16x3"], ids=["f32", "bf16x3"])
+def test_endtoend_adversarial_sign_branch(dtype):
+    """model_type endtoend: recon_w*recon - sex_w*sex + util_w*util - conf_w*confusion
+    (speechbrain_convae_train.py:111-121), including a non-zero confusion weight"""
+    from tests import smoke_step
+    smoke_step.run_teacher_forced(dtype, steps=2, model_type="endtoend",
+                                  weights=dict(recon=0.3, sex=0.6, utility=0.0, confusion=0.2))
+    # and its "sex only" sub-branch (:112-113)
+    smoke_step.run_teacher_forced(dtype, steps=1, model_type="endtoend",
+                                  weights=dict(recon=0.0, sex=0.7, utility=0.0, confusion=0.2))
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, "bf16x3"], ids=["f32", "bf16x3"])
+def test_epoch_parity_schedule_both_halves(dtype):
+    """HEAD's schedule (speechbrain_convae_train.py:212-235): odd epoch = only the sex classifier
+    trains (sex 0.5; encoder + decoder frozen: the backward stops at the classifier input), even
+    epoch = classifier frozen, encoder/decoder train against it (sex 0.8).  The sequence
+    odd, odd, even, odd also exercises torch 1.10's zero-filled gradients of frozen parameters
+    (Adam keeps moving them on their moments)."""
+    from tests import smoke_step
+    smoke_step.run_teacher_forced(dtype, steps=4, epoch_parity_schedule=True, epochs=[1, 1, 2, 3])
+
+
 def test_frozen_classifier_and_recon_only():
     """the reference's requires_grad toggling by name (speechbrain_convae_train.py:219-235) and
     config 1 (recon 1.0 only, MSE): frozen parameters get no gradient, the rest still match."""
