@@ -143,6 +143,25 @@ def cpu_model():
     return "unknown"
 
 
+def usable_cores():
+    """cores this process may really use: the affinity mask, capped by the cgroup CPU quota (the
+    GPU box hands a 1-GPU job a 16-CPU share of a much larger host: an OpenMP pool sized by the
+    affinity mask alone oversubscribes it many times over) and by 16."""
+    n = len(os.sched_getaffinity(0))
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    return max(1, min(n, 16))
+
+
+def note(msg):
+    """progress on stderr (stdout carries exactly one JSON line)"""
+    print(f"[bench] {msg}", file=sys.stderr, flush=True)
+
+
 def cpu_baseline():
     """the oracle (CPU restatement of the reference step, the same ATen CPU
     kernels the reference executes) at shape M, B = 10, every core this process may use, 2 warm-up
@@ -150,8 +169,9 @@ def cpu_baseline():
     import torch
     from oracle.train_step import OracleTrainer
     from oracle.features import synthetic_wave
-    threads = len(os.sched_getaffinity(0))
+    threads = usable_cores()
     Bc, warm, steps = 10, 2, 5
+    note(f"cpu baseline: oracle step, B={Bc}, {threads} threads, {warm}+{steps} steps")
     tr = OracleTrainer(threads=threads)
     wav = synthetic_wave(Bc, N_SAMPLES, seed=8886)
     lens, gender = torch.ones(Bc), torch.arange(Bc) % 2
@@ -162,9 +182,10 @@ def cpu_baseline():
         t0 = time.perf_counter()
         tr.fit_batch(wav, lens, gender)
         ts.append(time.perf_counter() - t0)
+        note(f"cpu baseline step {ts[-1]:.2f} s")
     dt = statistics.median(ts)
     return {"value": Bc * 1008 / dt, "unit": "frames/s", "cores": threads, "kind": "port",
-            "cpu_model": cpu_model(), "s_per_step": dt,
+            "cpu_model": cpu_model(), "s_per_step": dt, "cores_in_affinity_mask": len(os.sched_getaffinity(0)),
             "sample": f"oracle train step (torch CPU fp32, {threads} threads), shape M: B={Bc} x T=1008 "
                       f"frames, {warm} warm-up + median of {steps} timed steps"}
 
@@ -303,6 +324,8 @@ def main(argv=None):
                                      profile_key="conv_gemm(128,128,1,1)")
     frames = world * args.batch * T * args.steps
     value = frames / elapsed
+    if rank == 0:
+        note(f"B={args.batch}: {value:.4g} frames/s, {elapsed / args.steps * 1e3:.3f} ms/step")
     b10 = None
     if not args.no_b10 and args.batch != 10 and args.samples == N_SAMPLES:
         e10, l10, _ = run_config(args, 10, rank, world, device)

@@ -90,6 +90,15 @@ int sa_conv_gemm(int dtype, int cin, int cout, int sa, int u, const SaConvArgs* 
 int sa_abi_sizeof(int which);
 int sa_conv_gemm_ntiles(int cin, int cout, int u, int Lout);
 int sa_conv_gemm_set_tile_rows(int rows);   /* tuning knob: 0 (default policy), 64 or 128 */
+/* Geometry of a launch with this dtype code and shape: *ntiles = slabs per utterance of nb_colsum /
+ * pro_stats ([B][*ntiles][cin] / [B][*ntiles][cin][2]), *nslabs = statistics slabs per utterance
+ * (`stats` is [B][*nslabs][cout][2]); the reducers sum slabs in index order.  The f32 and bf16x3 policies run
+ * on the two-groups-in-anti-phase kernel (sa_conv_pp.hip), whose waves write one slab per wave that
+ * shares a column block; sa_conv_gemm_set_impl(0) routes them to the one-tile-per-workgroup kernel
+ * (A/B timing).  sa_conv_pp_set_tile_rows: 0 (policy), 64 or 128. */
+int sa_conv_gemm_geometry(int dtype, int cin, int cout, int u, int Lout, int* ntiles, int* nslabs);
+int sa_conv_gemm_set_impl(int pingpong);
+int sa_conv_pp_set_tile_rows(int rows);
 
 /* fp32 master weights -> fragment-major MFMA operand image (K = GEMM reduction channels,
  * N = produced channels; element W(t,k,n) = src[k*sk + n*sn + t*st]).

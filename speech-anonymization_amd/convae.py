@@ -258,6 +258,9 @@ def _noise(model, B, device):
 class _ConvAEFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, model, names, feats, *params):
+        # an output the loss does not use arrives as None in backward (not as a zero tensor): the
+        # parameters that only feed it then get no gradient at all, like in the reference's graph
+        ctx.set_materialize_grads(False)
         P = dict(zip(names, params))
         dt = model.act_dtype
         train = model.training
@@ -535,8 +538,16 @@ class _ConvAEFn(torch.autograd.Function):
             else:
                 run_convT_wgrad(key, x, dy, cin, cout, Mrows, False)
 
-        if d_recon is None:
-            d_recon = torch.zeros(B, T, 80, device=dev)
+        # an output the loss does not use (the endtoend "sex only" branch,
+        # speechbrain_convae_train.py:112-113, leaves recon out of the graph): like autograd in the
+        # reference, the parameters that only feed that output get NO gradient (None, so that Adam
+        # skips them) rather than zeros
+        recon_unused = d_recon is None
+        if recon_unused:
+            for k in need:
+                if k.startswith("decoder"):
+                    need[k] = False
+            need_stage["decoder"] = False
         if d_logp is None:
             d_logp = torch.zeros(B, 2, device=dev)
 
@@ -589,6 +600,8 @@ class _ConvAEFn(torch.autograd.Function):
             return (None, None, None) + grads
 
         # ======================= decoder =======================
+        if recon_unused:
+            d_recon = torch.zeros(B, T, 80, device=dev)
         g_rec = d_recon.reshape(B, Ltot).contiguous().float()
         if need["decoder.8.bias"]:
             setg("decoder.8.bias", ops.sum_partials(g_rec.view(4 * B, Ltot // 4), 1, n=Ltot // 4).sum())

@@ -25,7 +25,12 @@
 //              normalisation-backward statistics of the layer above (`ep_*`).
 #include "sa_common.h"
 
-#define SA_MAX_HALO 16
+// -DSA_ABL=<mask>: timing-only ablation builds (tools/conv_ablate.py; WRONG numerics, never shipped):
+//   1 no MFMA   2 weight fragments loaded once   4 no epilogue   8 no prologue transform
+//   16 A fragments loaded once   32 no prologue row loads
+#ifndef SA_ABL
+#define SA_ABL 0
+#endif
 // -DSA_CONV_STAMPS: diagnostic build (tools/conv_stamps.py) that stamps s_memtime at the phase
 // boundaries of a few workgroups; no stamp exists in the normal build.
 #ifdef SA_CONV_STAMPS
@@ -43,40 +48,7 @@ extern "C" int sa_conv_dbg_read(unsigned long long* out) {
 #define SA_STAMP_RT(i)
 #endif      // max (largest - smallest) tap row offset the prologue is sized for
 
-template <typename T, int CIN, int COUT, int SA, int U, int TM>
-struct ConvCfg {
-  typedef Pol<T> P;
-  typedef typename P::store_t S;
-  typedef typename P::lds_t LT;
-  static constexpr int VEC = P::VEC;                // storage elements per 16-byte chunk
-  static constexpr int KS = P::KS;
-  static constexpr int KSTEPS = CIN / KS;
-  static constexpr int NT = COUT / 32;
-  static constexpr int VT = NT * U;                 // virtual n-tiles (phase, n-tile)
-  static constexpr int BMB = TM / U;                // base rows per workgroup (TM output rows)
-  static constexpr int WN = VT >= 4 ? 4 : VT;       // waves along N
-  static constexpr int WM = 4 / WN;                 // waves along M
-  static constexpr int VPW = VT / WN;               // virtual n-tiles per wave
-  static constexpr int MT = BMB / (32 * WM);        // 32-row m-tiles per wave
-  static constexpr int APITCH = CIN + P::PAD;       // LDS operand pitch (lds_t elements)
-  static constexpr int OPITCH = COUT + (sizeof(S) == 2 ? 8 : 4);
-  static constexpr int CHI = CIN / VEC;             // 16-byte chunks per input row
-  static constexpr int RPPI = 256 / CHI;
-  static constexpr int OVEC = 16 / sizeof(S);
-  static constexpr int CHO = COUT / OVEC;
-  static constexpr int RPPO = 256 / CHO;
-  static_assert(MT >= 1 && VT % WN == 0, "tile shape");
-  static size_t tile_bytes(int nrows) {
-    size_t a = (size_t)P::NPL * nrows * APITCH * sizeof(LT);
-    size_t o = (size_t)TM * OPITCH * sizeof(S);
-    size_t m = a > o ? a : o;
-    return (m + 15) & ~(size_t)15;
-  }
-  static size_t lds_bytes(int nrows) {                 // the statistics scratch overlays the tile
-    size_t t = tile_bytes(nrows), r = (size_t)RPPO * COUT * 2 * sizeof(float);
-    return t > r ? t : r;
-  }
-};
+#include "sa_conv_cfg.h"
 
 template <typename T, int CIN, int COUT, int SA, int U, int TM, bool PRO2>
 // (256, 2): with an explicit minimum of resident workgroups hipcc allocates one unified register
@@ -127,6 +99,7 @@ __global__ __launch_bounds__(256, 2) void sa_conv_gemm_kernel(SaConvArgs a, int 
     for (int i = 0; i < NIT; ++i) {
       const int r = r0 + i * C::RPPI, g = gbase + r;
       raw[i] = make_uint4(0, 0, 0, 0);
+      if (!(SA_ABL & 32) || a.B < 0)
       if (r < a.nrows && g >= 0 && g < a.Lin) raw[i] = *reinterpret_cast<const uint4*>(xb + (size_t)g * CIN);
     }
     // PRO2 (normalisation-backward prologue, SaConvArgs.nb_*): the rows are d z of the layer above;
@@ -140,6 +113,7 @@ __global__ __launch_bounds__(256, 2) void sa_conv_gemm_kernel(SaConvArgs a, int 
       for (int i = 0; i < NIT; ++i) {
         const int r = r0 + i * C::RPPI, g = gbase + r;
         raw2[i] = make_uint4(0, 0, 0, 0);
+        if (!(SA_ABL & 32) || a.B < 0)
         if (r < a.nrows && g >= 0 && g < a.Lin) raw2[i] = *reinterpret_cast<const uint4*>(x2 + (size_t)g * CIN);
       }
 #pragma unroll
@@ -181,7 +155,9 @@ __global__ __launch_bounds__(256, 2) void sa_conv_gemm_kernel(SaConvArgs a, int 
         }
       }
     };
-    if constexpr (PRO2) {
+    if ((SA_ABL & 8) && a.B > 0) {
+      stage_rows([](float*, int, int) {});
+    } else if constexpr (PRO2) {
       stage_rows([&](float* f, int i, int g) {
         float y[VEC];
         tr::unpack(raw2[i], y);
@@ -337,10 +313,13 @@ __global__ __launch_bounds__(256, 2) void sa_conv_gemm_kernel(SaConvArgs a, int 
       load_a(0, 0);
 #pragma unroll
       for (int ku = 0; ku < KU; ++ku) {
-        if (ku + 1 < KU) load_a((ku + 1) & 1, ku + 1);
+        if (ku + 1 < KU && (!(SA_ABL & 16) || a.B < 0)) load_a((ku + 1) & 1, ku + 1);
 #pragma unroll
         for (int mt = 0; mt < C::MT; ++mt) {
-          if constexpr (P::NPL == 2) {
+          if constexpr ((SA_ABL & 1) != 0) {
+            asm volatile("" :: "v"(ah[ku & 1][mt]), "v"(bq[0][ku]));
+            if constexpr (P::NPL == 2) asm volatile("" :: "v"(al[ku & 1][mt]), "v"(bq[1][ku]));
+          } else if constexpr (P::NPL == 2) {
             acc[v][mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[ku & 1][mt], bq[0][ku], acc[v][mt], 0, 0, 0);
             acc[v][mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[ku & 1][mt], bq[1][ku], acc[v][mt], 0, 0, 0);
             acc[v][mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[ku & 1][mt], bq[0][ku], acc[v][mt], 0, 0, 0);
@@ -352,16 +331,28 @@ __global__ __launch_bounds__(256, 2) void sa_conv_gemm_kernel(SaConvArgs a, int 
     };
     Frag b0[P::NPL][KU], b1[P::NPL][KU];
     load_group(b0, 0);
+    if ((SA_ABL & 2) && a.B > 0) load_group(b1, 1);
     for (int g = 0; g < G; g += 2) {
-      if (g + 1 < G) load_group(b1, g + 1);
+      if (g + 1 < G && (!(SA_ABL & 2) || a.B < 0)) load_group(b1, g + 1);
       compute_group(b0, g);
       if (g + 1 < G) {
-        if (g + 2 < G) load_group(b0, g + 2);
+        if (g + 2 < G && (!(SA_ABL & 2) || a.B < 0)) load_group(b0, g + 2);
         compute_group(b1, g + 1);
       }
     }
   }
   SA_STAMP(3);
+  if ((SA_ABL & 4) && a.B > 0) {
+    float t = 0.0f;
+#pragma unroll
+    for (int v = 0; v < C::VPW; ++v)
+#pragma unroll
+      for (int mt = 0; mt < C::MT; ++mt)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) t += acc[v][mt][i];
+    if (t == 1.2345e-33f) reinterpret_cast<float*>(a.y)[tid] = t;       // keeps the accumulators live
+    return;
+  }
   constexpr int NOT = TM / C::RPPO;
   const int ec = tid % C::CHO, er0 = tid / C::CHO;
   __syncthreads();                                   // every wave is done reading As
@@ -545,10 +536,41 @@ static int tile_rows(int cin, int cout, int u) {
   return 64;
 }
 
-// number of (sum, sumsq) partial tiles per utterance the epilogue writes
+// number of (sum, sumsq) partial tiles per utterance the epilogue writes (one-tile-per-workgroup kernel)
 extern "C" int sa_conv_gemm_ntiles(int cin, int cout, int u, int Lout) {
   const int tm = tile_rows(cin, cout, u);
   return sa_div_up(sa_div_up(Lout, u), tm / u);
+}
+
+// ---- implementation choice: sa_conv_gemm_set_impl(1) routes the f32 and bf16x3 policies to the
+// two-groups-in-anti-phase kernel (sa_conv_pp.hip).  Default 0: on the round-2 measurements
+// (profiles/r02_conv_structure_experiments.md) it ties the one-tile kernel on the forward launches
+// (370 vs 370 us, 128->128, B = 32) and loses on the fused data gradients (614 vs 450 us).
+int sa_conv_pp_dispatch(int dtype, int cin, int cout, int sa, int u, const SaConvArgs* a, hipStream_t st);
+int sa_pp_tile_rows(int cin, int cout, int u);
+int sa_pp_share(int cout);
+static int g_use_pp = 0;
+extern "C" int sa_conv_gemm_set_impl(int pp) {
+  if (pp != 0 && pp != 1) return -22;
+  g_use_pp = pp;
+  return 0;
+}
+static bool uses_pp(int dtype) { return g_use_pp && (dtype == SA_F32 || dtype == SA_BF16X3); }
+
+// slabs per utterance of nb_colsum / pro_stats ([B][*ntiles][cin](x2)) and of `stats`
+// ([B][*nslabs][cout][2]) of a launch with this dtype code and shape
+extern "C" int sa_conv_gemm_geometry(int dtype, int cin, int cout, int u, int Lout, int* ntiles, int* nslabs) {
+  if (!ntiles || !nslabs || cin <= 0 || cout <= 0 || u <= 0 || Lout <= 0) return -22;
+  if (uses_pp(dtype)) {
+    const int tm = sa_pp_tile_rows(cin, cout, u);
+    const int nt = sa_div_up(sa_div_up(Lout, u), tm / u);
+    *ntiles = nt * 4;                      // nb_colsum / pro_stats: one slab per wave of the tile's group
+    *nslabs = nt * sa_pp_share(cout);
+  } else {
+    *ntiles = sa_conv_gemm_ntiles(cin, cout, u, Lout);
+    *nslabs = *ntiles;
+  }
+  return 0;
 }
 
 template <typename T, int CI, int CO, int S, int UU, bool PRO2 = false>
@@ -591,6 +613,7 @@ extern "C" int sa_conv_gemm(int dtype, int cin, int cout, int sa, int u, const S
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   if (!a || !a->x || !a->wp || !a->y || a->B <= 0 || a->Lin <= 0 || a->Lout <= 0) return -22;
   if (a->ep_mode < 0 || a->ep_mode > 2 || (a->ep_mode && !a->ep_x)) return -22;
+  if (uses_pp(dtype)) return sa_conv_pp_dispatch(dtype, cin, cout, sa, u, a, st);
   SA_CONV_CASE(32, 64, 2, 1)
   SA_CONV_CASE(64, 64, 1, 1)
   SA_CONV_CASE(64, 128, 2, 1)

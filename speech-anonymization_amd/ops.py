@@ -140,10 +140,24 @@ class PackedWeights:
 
 
 @functools.lru_cache(maxsize=None)
-def _conv_ntiles(cin, cout, u, Lout):
-    """statistics tiles per utterance of a launch (cached: the tile policy is fixed per process;
-    whoever calls sa_conv_gemm_set_tile_rows must do so before the first launch)"""
-    return L.load().sa_conv_gemm_ntiles(cin, cout, u, Lout)
+def _conv_geometry(code, cin, cout, u, Lout):
+    """(row tiles, statistics slabs) per utterance of a launch (cached: kernel choice and tile
+    policy are fixed per process; conv_impl() clears the cache when it switches them)"""
+    nt, ns = C.c_int(0), C.c_int(0)
+    L.check(L.load().sa_conv_gemm_geometry(code, cin, cout, u, Lout, C.byref(nt), C.byref(ns)),
+            "sa_conv_gemm_geometry")
+    return nt.value, ns.value
+
+
+def conv_impl(pingpong=False, tile_rows=0, pp_rows=0):
+    """kernel choice for the f32 / bf16x3 policies (A/B timing, kernel tests): the
+    one-tile-per-workgroup kernel (default) or the two-groups-in-anti-phase kernel
+    (sa_conv_pp.hip); tile-row knobs of both (0 = policy)."""
+    lib = L.load()
+    L.check(lib.sa_conv_gemm_set_impl(int(bool(pingpong))), "sa_conv_gemm_set_impl")
+    L.check(lib.sa_conv_gemm_set_tile_rows(int(tile_rows)), "sa_conv_gemm_set_tile_rows")
+    L.check(lib.sa_conv_pp_set_tile_rows(int(pp_rows)), "sa_conv_pp_set_tile_rows")
+    _conv_geometry.cache_clear()
 
 
 def conv_gemm(x, wp, bias, cin, cout, sa, u, phases, Lout, s1=None, t1=None, s2=None, t2=None,
@@ -160,8 +174,9 @@ def conv_gemm(x, wp, bias, cin, cout, sa, u, phases, Lout, s1=None, t1=None, s2=
     B, Lin, _ = x.shape
     assert x.shape[2] == cin
     y = out if out is not None else torch.empty(B, Lout, cout, dtype=x.dtype, device=x.device)
-    nt = _conv_ntiles(cin, cout, u, Lout)
-    stats = torch.empty(B, nt, cout, 2, dtype=torch.float32, device=x.device) if want_stats else None
+    kc = L.dt_code(x.dtype) if code is None else code
+    nt, nslab = _conv_geometry(kc, cin, cout, u, Lout)
+    stats = torch.empty(B, nslab, cout, 2, dtype=torch.float32, device=x.device) if want_stats else None
     a = L.SaConvArgs()
     a.x, a.wp, a.bias, a.y = _f(x), _f(wp), _f(bias), _f(y)
     a.s1, a.t1, a.s2, a.t2 = _f(s1), _f(t1), _f(s2), _f(t2)
@@ -192,8 +207,7 @@ def conv_gemm(x, wp, bias, cin, cout, sa, u, phases, Lout, s1=None, t1=None, s2=
         if ep.get("g2k") is not None:
             a.ep_g2k1, a.ep_g2k2, a.ep_g2k3 = (_f(t) for t in ep["g2k"])
     e0 = PROFILE.start(f"conv_gemm({cin},{cout},{sa},{u})") if PROFILE.key else None
-    L.check(lib.sa_conv_gemm(L.dt_code(x.dtype) if code is None else code, cin, cout, sa, u,
-                             C.byref(a), L.stream()),
+    L.check(lib.sa_conv_gemm(kc, cin, cout, sa, u, C.byref(a), L.stream()),
             f"sa_conv_gemm({cin},{cout},{sa},{u})")
     if e0 is not None:
         ntap = sum(len(p) for p in phases)

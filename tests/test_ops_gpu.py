@@ -600,3 +600,50 @@ def test_wgrad_from_cached_operand_is_bit_identical(cfg):
               code=L.BF16X1F)
     ops.wgrad(a_out, dy, cin, cout, sa, u, taps, Mrows, d2, strides, code=L.BF16X1F, x_pre=True)
     assert torch.equal(d1, d2)
+
+
+@pytest.mark.parametrize("layer", [LAYERS[0], LAYERS[3], LAYERS[6], LAYERS[7], LAYERS[8]],
+                         ids=["enc2", "enc11", "tdnn6", "dec1", "dec5"])
+@pytest.mark.parametrize("dt", ["bf16x3", torch.float32], ids=["bf16x3", "f32"])
+def test_pingpong_conv_kernel(layer, dt):
+    """the opt-in two-groups-in-anti-phase kernel (sa_conv_pp.hip, ops.conv_impl(pingpong=True)):
+    forward + statistics slabs, data gradient, at a ragged length and at a training length"""
+    from speech_anonymization_amd import ops
+    ops.conv_impl(pingpong=True)
+    try:
+        _conv_case(layer, dt, 3, 517)
+        _conv_case(layer, dt, 2, {32: 80640, 64: 40320, 128: 20160}[layer[1]])
+    finally:
+        ops.conv_impl(pingpong=False)
+
+
+def test_pingpong_conv_kernel_in_the_model():
+    """whole model forward + backward on the ping-pong kernel == on the default kernel (same
+    products, another summation order of the statistics slabs)"""
+    from oracle.convae import numpy_params
+    from oracle.features import synthetic_feats
+    from speech_anonymization_amd import ops
+    from speech_anonymization_amd.convae import ConvAutoencoder
+    feats = synthetic_feats(4, 144, seed=3).to(dev())
+    gender = (torch.arange(4) % 2).to(dev())
+    out = []
+    for pp in (False, True):
+        ops.conv_impl(pingpong=pp)
+        try:
+            m = ConvAutoencoder(precision="bf16x3", pooling_noise=None)
+            m.load_state_dict(numpy_params(8886))
+            m.to(dev()).train()
+            recon, logp = m(feats)
+            _, g_r = ops.recon_loss(recon.detach().contiguous(), feats.contiguous(), "l1")
+            _, dn, _ = ops.cls_losses(logp.detach(), gender)
+            torch.autograd.backward([recon, logp], [0.1 * g_r.view_as(recon), 0.9 * dn])
+            torch.cuda.synchronize()
+            out.append((recon.detach().clone(), logp.detach().clone(),
+                        {k: p.grad.clone() for k, p in m.named_parameters()}))
+        finally:
+            ops.conv_impl(pingpong=False)
+    from tests.test_convae_gpu import NULL_BIAS
+    assert rel_mse(out[1][0], out[0][0]) < 1e-10 and rel_mse(out[1][1], out[0][1]) < 1e-8
+    for k, g in out[0][2].items():
+        if k not in NULL_BIAS:
+            assert rel_mse(out[1][2][k], g) < 1e-6, k
