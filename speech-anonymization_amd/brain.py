@@ -47,11 +47,17 @@ class NoamScheduler:
 
     def __call__(self, opt):
         self.n_steps += 1
-        current_lr = opt.param_groups[0]["lr"]
+        current_lr = getattr(opt, "_sa_host_lr", None)
+        if current_lr is None:
+            current_lr = opt.param_groups[0]["lr"]
         lr = self.lr_initial * self.normalize * min(self.n_steps ** (-0.5),
                                                     self.n_steps * self.n_warmup_steps ** (-1.5))
         for g in opt.param_groups:
-            g["lr"] = lr
+            if torch.is_tensor(g["lr"]):      # capturable optimizer (hipGraph mode): the rate lives on the device
+                g["lr"].fill_(lr)
+            else:
+                g["lr"] = lr
+        opt._sa_host_lr = lr
         self.current_lr = current_lr
         return current_lr, lr
 
@@ -98,6 +104,9 @@ class Brain:
         self.max_grad_norm = float(run_opts.get("max_grad_norm", 5.0))
         self.nonfinite_patience = int(run_opts.get("nonfinite_patience", 3))
         self.lazy_finite_check = bool(run_opts.get("lazy_finite_check", True))
+        # hip_graph: capture the whole train step (forward, losses, backward, clip, Adam) in a
+        # hipGraph per batch shape and replay it (single process; see SexAnonymizationTraining)
+        self.hip_graph = bool(run_opts.get("hip_graph", False)) and self.device.type == "cuda"
         self.distributed_launch = bool(run_opts.get("distributed_launch", sdist.is_distributed()))
         self.modules = torch.nn.ModuleDict(modules or {})
         self.opt_class = opt_class
@@ -137,36 +146,72 @@ class Brain:
             given = getattr(self.opt_class, "keywords", None) or {}
             if base is torch.optim.Adam and "fused" not in given and params and all(p.is_cuda for p in params):
                 try:        # PyTorch's single-launch Adam: same update, ~8 fewer launches per step
-                    self.optimizer = self.opt_class(params, fused=True)
+                    if self.hip_graph:
+                        # capturable: step counts and the learning rate are device tensors, so a
+                        # captured optimizer.step() follows the Noam schedule on replay
+                        self.optimizer = self.opt_class(params, fused=True, capturable=True)
+                        for g in self.optimizer.param_groups:
+                            self.optimizer._sa_host_lr = float(g["lr"])
+                            g["lr"] = torch.tensor(float(g["lr"]), dtype=torch.float32, device=self.device)
+                    else:
+                        self.optimizer = self.opt_class(params, fused=True)
                     return
                 except (TypeError, RuntimeError):
-                    pass
+                    self.hip_graph = False
             self.optimizer = self.opt_class(params)
 
     def check_gradients(self, loss):
         """speechbrain semantics: count non-finite losses (raise after `nonfinite_patience`),
         otherwise clip the global gradient norm to max_grad_norm."""
-        finite = self._finite_check(loss)
-        if not finite:
-            self.nonfinite_count += 1
+        bad = self._count_nonfinite(loss)
+        if bad:
+            self.nonfinite_count += bad
             if self.nonfinite_count > self.nonfinite_patience:
                 raise ValueError("Loss is not finite and patience is exhausted.")
-            return False
+            if not (self.lazy_finite_check and loss.is_cuda):
+                return False
         params = getattr(self, "_clip_params", None)
         if params is None:          # walking the module tree for 56 parameters costs 0.3 ms per step
             params = self._clip_params = list(self.modules.parameters())
         torch.nn.utils.clip_grad_norm_(params, self.max_grad_norm)
         return True
 
-    def _finite_check(self, loss):
-        """`torch.isfinite(loss)` read on the host would stall the CPU until the GPU has finished
-        the whole backward of this step, every step.  With lazy_finite_check (run_opts, default
-        True on GPU) the flag of the PREVIOUS step is read instead (already complete), so a
-        non-finite loss is counted one step late; False restores the synchronous check."""
+    def _count_nonfinite(self, loss):
+        """number of non-finite losses newly known to the host.  `torch.isfinite(loss)` read on the
+        host would stall the CPU until the GPU has finished the whole backward of this step, every
+        step.  With lazy_finite_check (run_opts, default True on GPU) the flag is accumulated in a
+        device counter whose value travels to pinned host memory with an asynchronous copy; the
+        host looks at the newest copy that has ALREADY arrived (event query, never a wait), so a
+        non-finite loss is counted a step or two late and nothing synchronises.  False restores
+        the synchronous check.  Capture-safe (hipGraph mode): the counter update and the copy are
+        recorded in the graph, the event is recorded by the replaying host code."""
         if not (self.lazy_finite_check and loss.is_cuda):
-            return bool(torch.isfinite(loss))
-        prev, self._pending_finite = getattr(self, "_pending_finite", None), torch.isfinite(loss.detach())
-        return True if prev is None else bool(prev)
+            return 0 if bool(torch.isfinite(loss)) else 1
+        st = getattr(self, "_finite_state", None)
+        if st is None:
+            st = self._finite_state = dict(dev=torch.zeros((), dtype=torch.int32, device=loss.device),
+                                           host=torch.zeros((), dtype=torch.int32).pin_memory(),
+                                           event=torch.cuda.Event(), seen=0, pending=False)
+        new = self._poll_nonfinite()
+        st["dev"].add_((~torch.isfinite(loss.detach())).to(torch.int32))
+        st["host"].copy_(st["dev"], non_blocking=True)
+        if not torch.cuda.is_current_stream_capturing():
+            st["event"].record()
+            st["pending"] = True
+        return new
+
+    def _poll_nonfinite(self, wait=False):
+        st = getattr(self, "_finite_state", None)
+        if st is None or not st["pending"]:
+            return 0
+        if wait:
+            st["event"].synchronize()
+        elif not st["event"].query():
+            return 0
+        st["pending"] = False
+        total = int(st["host"])
+        new, st["seen"] = total - st["seen"], total
+        return max(new, 0)
 
     def fit_batch(self, batch):
         outputs = self.compute_forward(batch, Stage.TRAIN)
@@ -312,8 +357,83 @@ class SexAnonymizationTraining(Brain):
                         g = z[p] = torch.zeros_like(p)
                     p.grad = g
 
+    # ---- hipGraph mode (run_opts hip_graph=True, one process): the ~230 launches of a step are
+    # captured once per (batch shape, schedule state) after a few eager steps and replayed; the
+    # host then issues one graph launch per step instead of ~230 kernel launches (at B = 10 the
+    # eager step is bound by the host's launch rate).  Noam's rate and Adam's step counts live in
+    # device tensors (capturable Adam); the non-finite-loss flag is read one step late from pinned
+    # memory.  Falls back to the eager path for gradient accumulation > 1 and under DDP.
+    GRAPH_WARMUP = 3
+
+    def _graph_key(self, batch):
+        hp = self.hparams
+        wavs, lens = batch.sig
+        nrm = self.modules["normalize"] if "normalize" in self.modules else None
+        upd = nrm is not None and hp.epoch_counter.current < getattr(nrm, "update_until_epoch", 0)
+        return (tuple(wavs.shape), str(wavs.dtype), hp.model_type, float(hp.recon_loss_weight),
+                float(hp.sex_loss_weight), float(hp.utility_loss_weight),
+                float(getattr(hp, "confusion_loss_weight", 0.0)), bool(upd),
+                tuple(p.requires_grad for p in self.modules.ConvAE.parameters()))
+
+    def _step_core(self, batch):
+        predictions = self.compute_forward(batch, Stage.TRAIN)
+        loss = self.compute_objectives(predictions, batch, Stage.TRAIN)
+        loss.backward()
+        if getattr(self.hparams, "epoch_parity_schedule", False):
+            self._zero_grads_of_frozen()
+        self.check_gradients(loss)
+        self.optimizer.step()
+        return loss.detach()
+
+    def _fit_batch_graph(self, batch):
+        batch = batch.to(self.device)
+        key = self._graph_key(batch)
+        graphs = self.__dict__.setdefault("_graphs", {})
+        ent = graphs.get(key)
+        if ent is None:
+            ent = graphs[key] = {"seen": 0}
+        if "graph" not in ent:
+            ent["seen"] += 1
+            if ent["seen"] <= self.GRAPH_WARMUP:            # eager (also builds every cache / pool)
+                self.optimizer.zero_grad(set_to_none=True)  # (static gradients of another graph)
+                loss = self._step_core(batch)
+                self.optimizer.zero_grad()
+                self.hparams.noam_annealing(self.optimizer)
+                return loss
+            wavs, lens = batch.sig
+            ent["wav"], ent["lens"] = wavs.clone(), lens.clone()
+            ent["gender"] = batch.gender.clone()
+            ent["batch"] = Batch(ent["wav"], ent["lens"], ent["gender"])
+            torch.cuda.synchronize()
+            self.nonfinite_count += self._poll_nonfinite(wait=True)      # nothing pending across the capture
+            g = torch.cuda.CUDAGraph()
+            self.optimizer.zero_grad(set_to_none=True)
+            with torch.cuda.graph(g):
+                ent["loss"] = self._step_core(ent["batch"])
+            ent["graph"] = g
+            # the capture itself does not execute the step: replay it for this batch below
+        wavs, lens = batch.sig
+        ent["wav"].copy_(wavs, non_blocking=True)
+        ent["lens"].copy_(lens, non_blocking=True)
+        ent["gender"].copy_(batch.gender, non_blocking=True)
+        bad = self._poll_nonfinite()                        # counter copies of earlier replays
+        if bad:
+            self.nonfinite_count += bad
+            if self.nonfinite_count > self.nonfinite_patience:
+                raise ValueError("Loss is not finite and patience is exhausted.")
+        ent["graph"].replay()
+        st = getattr(self, "_finite_state", None)
+        if st is not None:
+            st["event"].record()
+            st["pending"] = True
+        self.hparams.noam_annealing(self.optimizer)
+        return ent["loss"]
+
     def fit_batch(self, batch):
         self.apply_epoch_schedule()
+        if (self.hip_graph and self.hparams.gradient_accumulation == 1 and sdist.world_size() == 1
+                and self.optimizer is not None):
+            return self._fit_batch_graph(batch)
         predictions = self.compute_forward(batch, Stage.TRAIN)
         loss = self.compute_objectives(predictions, batch, Stage.TRAIN)
         (loss / self.hparams.gradient_accumulation).backward()

@@ -50,6 +50,42 @@ def test_epoch_parity_schedule_both_halves(dtype):
     smoke_step.run_teacher_forced(dtype, steps=4, epoch_parity_schedule=True, epochs=[1, 1, 2, 3])
 
 
+def test_hip_graph_step_equals_eager_steps():
+    """run_opts hip_graph=True: three eager steps, capture, then replays -- against the same steps
+    launched eagerly (same kernels in the same order; Adam differs only in where its bias
+    corrections are evaluated: on the device in the capturable form)."""
+    from oracle.convae import numpy_params
+    from tests import smoke_step
+    from speech_anonymization_amd.brain import Batch
+    dev = torch.device("cuda:0")
+    wav = smoke_step.make_wave(4, 11360)
+    batches = [Batch(wav * s, torch.tensor([1.0, 0.83, 0.61, 1.0]), torch.arange(4) % 2) for s in (1.0, 0.9, 0.8, 1.1, 0.7, 1.05, 0.95)]
+    runs = []
+    for graph in (False, True):
+        br = smoke_step.build("bf16x3", dev, numpy_params(8886))
+        if graph:
+            import functools
+            br.hip_graph, br.optimizer = True, None
+            br.init_optimizers()
+            assert torch.is_tensor(br.optimizer.param_groups[0]["lr"])
+        losses = []
+        for b in batches:
+            br.step += 1
+            losses.append(float(br.fit_batch(b)))
+        torch.cuda.synchronize()
+        if graph:
+            assert len(br._graphs) == 1 and "graph" in next(iter(br._graphs.values()))
+        runs.append((losses, {k: v.detach().clone() for k, v in br.modules["ConvAE"].state_dict().items()},
+                     br.hparams.noam_annealing.n_steps, br.modules["normalize"].count))
+    (l0, p0, n0, c0), (l1, p1, n1, c1) = runs
+    assert n0 == n1 == len(batches) and c0 == c1
+    for a, b in zip(l0, l1):
+        assert abs(a - b) <= 1e-5 * max(1.0, abs(a)), (l0, l1)
+    for k in p0:
+        if p0[k].dtype.is_floating_point:
+            assert float((p0[k] - p1[k]).abs().max()) <= 2e-6 + 1e-5 * float(p0[k].abs().max()), k
+
+
 def test_frozen_classifier_and_recon_only():
     """the reference's requires_grad toggling by name (speechbrain_convae_train.py:219-235) and
     config 1 (recon 1.0 only, MSE): frozen parameters get no gradient, the rest still match."""
