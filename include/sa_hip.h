@@ -234,13 +234,29 @@ int sa_cosine_loss(const float* x1, const float* x2, int B, int S, int D, float*
  * LeakyReLU -> BatchNorm1d(eval); StatisticsPooling over time with relative lengths. */
 /* wp: sa_pack_weights(SA_BF16X3, ...) image of the Conv1d weight zero-padded to Npad output channels
  * (Npad % 128 == 0; ntaps = K, K = Cin (% 16 == 0), N = Npad, sk = K, sn = Cin*K, st = 1) */
+/* mask (optional, [B][T][Cout] bytes): 1 where the LeakyReLU input was positive (for sa_tdnn_bwd_input) */
 int sa_tdnn_fwd(const float* x, const void* wp, const float* bias, const float* bn_s, const float* bn_t,
                 float* y, int B, int T, int Cin, int Cout, int Npad, int K, int dil, float slope,
-                void* stream);
+                unsigned char* mask, void* stream);
 int sa_time_pool(const float* x, const float* lens, const float* noise, int B, int T, int C, float eps,
                  float* out, void* stream);
 int sa_leaky_affine(const float* x, const float* s, const float* t, float slope, int M, int C, float* y,
                     void* stream);
+/* the same classifier INSIDE the training graph (models/EndToEnd.py:57-61,81: pretrained, frozen):
+ * gradient with respect to the input features only.
+ * sa_tdnn_bwd_input: dy [B][T][Cy], mask = the forward's LeakyReLU branch mask -> dxe [B][T + dil*(K-1)][Cin],
+ *   the data gradient on the range extended by the "same" padding; wp = split-bf16 image of the
+ *   Conv1d weight packed as a data-gradient operand (reduction Cred >= Cy, % 16; produced Npad >= Cin,
+ *   % 128).  sa_tdnn_fold applies the adjoint of the reflect padding: dxe -> dx [B][T][C].
+ * sa_time_pool_bwd: pooled = forward output without the noise offset.  */
+int sa_tdnn_bwd_input(const float* dy, const unsigned char* mask, const float* bn_s, const void* wp,
+                      float* dxe, int B, int T, int Cy, int Cred, int Cin, int Npad, int K, int dil,
+                      float slope, void* stream);
+int sa_tdnn_fold(const float* dxe, float* dx, int B, int T, int C, int pad, void* stream);
+int sa_time_pool_bwd(const float* x, const float* lens, const float* g, const float* pooled, int B,
+                     int T, int C, float eps, float* dx, void* stream);
+int sa_leaky_affine_bwd(const float* dy, const float* x, const float* s, float slope, int M, int C,
+                        float* dx, void* stream);
 
 /* ---- k-NN mutual information (sa_mi.hip): utils/ClusterMI.py:88-121,
  * utils/GroupSamplingMI.py:49-61, utils/mi_loss.py:14-17 ------------------------------ */

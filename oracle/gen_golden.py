@@ -43,8 +43,17 @@ def install_shim():
         def __init__(self):
             super().__init__(noise=None)
 
-    class EncoderClassifier:                               # never instantiated on this path
-        pass
+    class EncoderClassifier:
+        """the reference's models/EndToEnd.py builds its frozen gender classifier with
+        EncoderClassifier.from_hparams(source="/home/ubuntu/...") (:57-61): absolute paths of its
+        authors' machine and weights that are not in the repository.  The shim hands back the
+        oracle x-vector wrapper registered in FROM_HPARAMS (seeded weights) instead."""
+        FROM_HPARAMS = None
+
+        @classmethod
+        def from_hparams(cls, **_kw):
+            assert cls.FROM_HPARAMS is not None
+            return cls.FROM_HPARAMS
 
     pooling.StatisticsPooling = StatisticsPooling
     pretrained.EncoderClassifier = EncoderClassifier
@@ -111,6 +120,54 @@ def convae_fixture(tag, B, T, seed, recon_kind):
     np.savez_compressed(os.path.join(OUT, f"convae_{tag}.npz"), **d)
     print(f"convae_{tag}: loss={float(ref['loss']):.6f} gn={float(ref['gn']):.6f} "
           f"(oracle == reference: bit-exact)")
+
+
+def endtoend_fixture(B=3, T=36, seed=4):
+    """models/EndToEnd.py:ConvReconstruction (the reference's own class, its classifier =
+    the oracle x-vector wrapper via the shim) == oracle/endtoend.py, bit for bit; loss with the
+    adversarial signs of speechbrain_convae_train.py:111-121."""
+    from oracle import endtoend as OE
+    from oracle.features import synthetic_feats
+    import speechbrain.pretrained as sbp
+    clf = OE.OracleEncoderClassifier()
+    clf.load_state_dict(OE.numpy_params(clf, 1230))
+    clf.eval()
+    sbp.EncoderClassifier.FROM_HPARAMS = clf
+    from models.EndToEnd import ConvReconstruction as RefCR
+    rs = np.random.RandomState(seed)
+    feats = synthetic_feats(B, T, seed)
+    target = feats + torch.from_numpy(0.1 * rs.standard_normal((B, T, 80)).astype("float32"))
+    gender = torch.arange(B) % 2
+    w = dict(recon=0.4, sex=0.5, utility=0.0, confusion=0.1)
+    ora0 = OE.ConvReconstruction(clf)
+    enc_params = {k: v for k, v in OE.numpy_params(ora0, 8886).items() if k.startswith("encoder.")}
+
+    def run(model):
+        model.load_state_dict(enc_params, strict=False)
+        model.train()
+        model.sex_classifier.eval()
+        recon, logp = model(feats)
+        rl = L.recon_loss(recon, target, "l1")
+        sl = torch.nn.NLLLoss()(logp, gender)
+        cl = torch.nn.MSELoss()(logp, torch.ones(logp.shape) * (-0.6931))
+        loss = w["recon"] * rl - w["sex"] * sl + w["utility"] * 0.0 - w["confusion"] * cl
+        loss.backward()
+        grads = {k: p.grad.clone() for k, p in model.named_parameters() if k.startswith("encoder.")}
+        return dict(recon=recon.detach(), logp=logp.detach(), loss=loss.detach(), grads=grads)
+
+    ref, ora = run(RefCR()), run(ora0)
+    for k in ("recon", "logp", "loss"):
+        assert torch.equal(ref[k], ora[k]), f"oracle != reference on {k}"
+    for k in ref["grads"]:
+        assert torch.equal(ref["grads"][k], ora["grads"][k]), f"oracle != reference grad {k}"
+    d = dict(feats=feats.numpy(), target=target.numpy(), gender=gender.numpy(), recon=ref["recon"].numpy(),
+             logp=ref["logp"].numpy(), loss=ref["loss"].numpy(),
+             weights=np.array([w["recon"], w["sex"], w["utility"], w["confusion"]]))
+    for k, g in ref["grads"].items():
+        d["grad_sub/" + k] = sub(g)
+        d["grad_stat/" + k] = np.array([float(g.double().sum()), float(g.double().norm())])
+    np.savez_compressed(os.path.join(OUT, "endtoend_S.npz"), **d)
+    print(f"endtoend_S: loss={float(ref['loss']):.6f} (oracle == reference: bit-exact)")
 
 
 def loss_fixtures():
@@ -193,5 +250,6 @@ if __name__ == "__main__":
     torch.set_num_threads(1)        # deterministic CPU reductions
     convae_fixture("S", B=4, T=72, seed=1, recon_kind="l1")
     convae_fixture("S_mse", B=5, T=36, seed=2, recon_kind="mse")
+    endtoend_fixture()
     loss_fixtures()
     data_pins()

@@ -71,7 +71,8 @@ SYMBOLS = [
     "sa_pool_fwd", "sa_pool_nseg", "sa_pool_gather", "sa_pool_fin", "sa_pool_bwd", "sa_dense", "sa_colsums",
     "sa_bn2d_bwd", "sa_dense_wgrad", "sa_log_softmax", "sa_log_softmax_bwd",
     "sa_loss_workspace_bytes", "sa_recon_loss", "sa_cls_losses", "sa_cosine_loss",
-    "sa_tdnn_fwd", "sa_time_pool", "sa_leaky_affine", "sa_cluster_mi", "sa_fbank", "sa_fbank_table_elems", "sa_fbank_ntiles", "sa_fbank_scratch_bytes", "sa_fbank_normalize",
+    "sa_tdnn_fwd", "sa_time_pool", "sa_leaky_affine", "sa_tdnn_bwd_input", "sa_tdnn_fold", "sa_time_pool_bwd",
+    "sa_leaky_affine_bwd", "sa_cluster_mi", "sa_fbank", "sa_fbank_table_elems", "sa_fbank_ntiles", "sa_fbank_scratch_bytes", "sa_fbank_normalize",
 ]
 
 _lib = None

@@ -264,7 +264,11 @@ class Brain:
                         avg += (float(self.evaluate_batch(batch, Stage.VALID)) - avg) / n
                 self.on_stage_end(Stage.VALID, avg, epoch)
 
-    def evaluate(self, test_set, **_):
+    def on_evaluate_start(self, max_key=None, min_key=None):
+        pass
+
+    def evaluate(self, test_set, max_key=None, min_key=None, **_):
+        self.on_evaluate_start(max_key=max_key, min_key=min_key)
         self.on_stage_start(Stage.TEST, None)
         self.modules.eval()
         avg, n = 0.0, 0
@@ -318,9 +322,17 @@ class SexAnonymizationTraining(Brain):
                     + hp.utility_loss_weight * utility_loss)
         self.last_losses = dict(recon=recon_loss.detach(), sex=sex_loss.detach())
         if stage != Stage.TRAIN:
-            pred = sex_logits.argmax(dim=1)
-            self.eval_correct += int((pred == sex_label).sum())
-            self.eval_total += int(sex_label.numel())
+            # reference :130-149: accuracy of the model's own classifier head, and of the externally
+            # trained x-vector classifier on the original and on the reconstructed features
+            n = torch.tensor(sex_label.shape[0], device=sex_logits.device).unsqueeze(0)
+            self.sex_classification_acc.append(sex_logits.unsqueeze(0), sex_label.unsqueeze(0), n)
+            ext = getattr(self, "external_classifier", None)
+            if ext is not None:
+                with torch.no_grad():
+                    lo, _, _ = ext.classify_batch_feats(feats)
+                    lr, _, _ = ext.classify_batch_feats(reconstructed_speech.detach())
+                self.sex_classification_acc_extern_orig.append(lo.unsqueeze(0), sex_label.unsqueeze(0), n)
+                self.sex_classification_acc_extern.append(lr.unsqueeze(0), sex_label.unsqueeze(0), n)
         return loss
 
     def apply_epoch_schedule(self):
@@ -452,16 +464,49 @@ class SexAnonymizationTraining(Brain):
             loss = self.compute_objectives(predictions, batch, stage=stage)
         return loss.detach()
 
+    def load_external_classifier(self):
+        """reference :261-269 reloads the pretrained x-vector classifier from absolute paths at
+        every stage start; here it is an object handed over once: hparams["external_classifier"]
+        (xvector.EncoderClassifier) or None (no ACC_external columns)."""
+        ext = getattr(self.hparams, "external_classifier", None)
+        if ext is not None:
+            ext.eval()
+            ext.to(self.device)
+        return ext
+
     def on_stage_start(self, stage, epoch=None):
+        from .metrics import AccuracyStats, SimilarityMetricsStats
+        self.external_classifier = self.load_external_classifier()
         if stage != Stage.TRAIN:
-            self.eval_correct, self.eval_total = 0, 0
+            self.sex_classification_acc = AccuracyStats()
+            self.sex_classification_acc_extern = AccuracyStats()
+            self.sex_classification_acc_extern_orig = AccuracyStats()
+            self.utility_similarity_aggregator = SimilarityMetricsStats()
+
+    def on_evaluate_start(self, max_key=None, min_key=None):
+        """reference :404-416: average the checkpoints selected by max_key / min_key into the model"""
+        if self.checkpointer is None:
+            return
+        ckpts = self.checkpointer.find_checkpoints(max_key=max_key, min_key=min_key)
+        if not ckpts:
+            return
+        sd = self.checkpointer.average_checkpoints(ckpts, recoverable_name="model", device=self.device)
+        model = getattr(self.hparams, "model", None)
+        if model is not None:
+            model.load_state_dict(sd, strict=False)
+            model.eval()
 
     def on_stage_end(self, stage, stage_loss, epoch=None):
         stats = {"loss": stage_loss}
         if stage == Stage.TRAIN:
             self.train_stats = stats
             return
-        stats["ACC"] = self.eval_correct / max(1, self.eval_total)
+        stats["ACC"] = self.sex_classification_acc.summarize()
+        if self.external_classifier is not None:
+            stats["ACC_external"] = self.sex_classification_acc_extern.summarize()
+            stats["ACC_external_orig"] = self.sex_classification_acc_extern_orig.summarize()
+        if self.utility_similarity_aggregator.denom:          # only with a frozen ASR in the loop (8f-2)
+            stats["Utility_Retention"] = float(self.utility_similarity_aggregator.summarize())
         self.valid_stats = stats
         logger = getattr(self.hparams, "train_logger", None)
         if stage == Stage.VALID and sdist.if_main_process() and logger is not None:
@@ -470,7 +515,12 @@ class SexAnonymizationTraining(Brain):
                                          "optimizer": self.optimizer.__class__.__name__},
                              train_stats=self.train_stats, valid_stats=stats)
         if stage == Stage.VALID and sdist.if_main_process() and self.checkpointer is not None:
-            self.checkpointer.save(self, epoch, stats)
+            # reference :338-343
+            keys = {k: stats[k] for k in ("ACC_external", "Utility_Retention") if k in stats}
+            self.checkpointer.save_and_keep_only(self, epoch, dict(stats, **keys),
+                                                 max_keys=[k for k in ("Utility_Retention",) if k in stats],
+                                                 min_keys=[k for k in ("ACC_external",) if k in stats],
+                                                 num_to_keep=5)
 
 
 class FileTrainLogger:

@@ -64,6 +64,69 @@ class Checkpointer:
             shutil.rmtree(os.path.join(self.checkpoints_dir, old), ignore_errors=True)
         return path
 
+    # ---- speechbrain Checkpointer surface the reference calls (speechbrain_convae_train.py:338-343,
+    # 404-415): keep-only by metric, lookup by metric, checkpoint averaging
+    def _meta(self, name):
+        """CKPT.yaml of checkpoint `name` through the SAFE yaml loader (reference checkpoints hold
+        pickled tensors there: those files are skipped, never unpickled)."""
+        try:
+            m = yaml.safe_load(open(os.path.join(self.checkpoints_dir, name, "CKPT.yaml")))
+            return m if isinstance(m, dict) else {}
+        except (OSError, yaml.YAMLError):
+            return {}
+
+    def find_checkpoints(self, max_key=None, min_key=None, max_num_checkpoints=None):
+        """checkpoint directories, best first by `max_key` (highest) or `min_key` (lowest); most
+        recent first when neither is given."""
+        names = self._list()
+        metas = {n: self._meta(n) for n in names}
+        if max_key is not None:
+            names = sorted((n for n in names if max_key in metas[n]), key=lambda n: -float(metas[n][max_key]))
+        elif min_key is not None:
+            names = sorted((n for n in names if min_key in metas[n]), key=lambda n: float(metas[n][min_key]))
+        else:
+            names = sorted(names, key=lambda n: -float(metas[n].get("unixtime", 0.0)))
+        if max_num_checkpoints is not None:
+            names = names[:max_num_checkpoints]
+        return [os.path.join(self.checkpoints_dir, n) for n in names]
+
+    def save_and_keep_only(self, brain=None, epoch=None, meta=None, max_keys=(), min_keys=(), num_to_keep=1):
+        """save, then keep the union of: the `num_to_keep` best per key of max_keys / min_keys and
+        the `num_to_keep` most recent; delete the rest."""
+        path = self.save(brain, epoch, meta, num_to_keep=10 ** 9)
+        keep = set(self.find_checkpoints(max_num_checkpoints=num_to_keep))
+        for k in max_keys:
+            keep.update(self.find_checkpoints(max_key=k, max_num_checkpoints=num_to_keep))
+        for k in min_keys:
+            keep.update(self.find_checkpoints(min_key=k, max_num_checkpoints=num_to_keep))
+        for n in self._list():
+            full = os.path.join(self.checkpoints_dir, n)
+            if full not in keep:
+                shutil.rmtree(full, ignore_errors=True)
+        return path
+
+    @staticmethod
+    def average_checkpoints(ckpt_dirs, recoverable_name="model", device=None):
+        """element-wise mean of `<recoverable_name>.ckpt` over the given checkpoints (integer
+        tensors such as num_batches_tracked: floor of the mean), like
+        speechbrain.utils.checkpoints.average_checkpoints."""
+        avg, n = None, 0
+        for d in ckpt_dirs:
+            sd = torch.load(os.path.join(d, f"{recoverable_name}.ckpt"), map_location=device or "cpu",
+                            weights_only=True)
+            n += 1
+            if avg is None:
+                avg = {k: (v.clone().double() if v.dtype.is_floating_point else v.clone()) for k, v in sd.items()}
+            else:
+                for k, v in sd.items():
+                    avg[k] += v.double() if v.dtype.is_floating_point else v
+        if avg is None:
+            raise ValueError("no checkpoints to average")
+        ref = torch.load(os.path.join(ckpt_dirs[0], f"{recoverable_name}.ckpt"), map_location=device or "cpu",
+                         weights_only=True)
+        return {k: ((v / n).to(ref[k].dtype) if v.dtype.is_floating_point else torch.div(v, n, rounding_mode="floor"))
+                for k, v in avg.items()}
+
     def recover_if_possible(self, device=None, brain=None):
         """load the newest checkpoint into every recoverable (and brain.ckpt into `brain`);
         returns its path, or None when there is nothing to resume from."""

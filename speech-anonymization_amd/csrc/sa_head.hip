@@ -599,7 +599,7 @@ __global__ __launch_bounds__(256, 2) void sa_tdnn_fwd_kernel(const float* __rest
                                                              const float* __restrict__ bn_t,
                                                              float* __restrict__ y, int T, int Cin,
                                                              int Cout, int Npad, int K, int dil,
-                                                             float slope) {
+                                                             float slope, unsigned char* __restrict__ mask) {
   constexpr int PITCH = SA_TD_CK + 8, ROWS = SA_TD_BM + SA_TD_HALO, PLANE = ROWS * PITCH;
   __shared__ __attribute__((aligned(16))) bf16_t As[2 * PLANE];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wm = wave >> 1, wn = wave & 1;
@@ -672,6 +672,7 @@ __global__ __launch_bounds__(256, 2) void sa_tdnn_fwd_kernel(const float* __rest
           const int t = t0 + wm * 64 + mt * 32 + sa_acc_row(i, lane);
           if (t < T) {
             float v = acc[mt][nt][i] + bb;
+            if (mask) mask[((size_t)b * T + t) * Cout + n] = v > 0.0f;   // LeakyReLU branch, for the backward
             v = v > 0.0f ? v : v * slope;
             y[((size_t)b * T + t) * Cout + n] = fmaf(v, sc, sh);
           }
@@ -684,14 +685,207 @@ __global__ __launch_bounds__(256, 2) void sa_tdnn_fwd_kernel(const float* __rest
 // sk = K, sn = Cin*K, st = 1); Npad % 128 == 0, Cin % 16 == 0.
 extern "C" int sa_tdnn_fwd(const float* x, const void* wp, const float* bias, const float* bn_s,
                            const float* bn_t, float* y, int B, int T, int Cin, int Cout, int Npad, int K,
-                           int dil, float slope, void* stream) {
+                           int dil, float slope, unsigned char* mask, void* stream) {
   if (!x || !wp || !y || B <= 0 || T <= 0 || Cin <= 0 || Cout <= 0 || K < 1 || !(K & 1) || dil < 1 ||
       dil * (K - 1) / 2 >= T || dil * (K - 1) > SA_TD_HALO || Cin % 16 || Npad % SA_TD_BN || Npad < Cout)
     return -22;
   dim3 grid(sa_div_up(T, SA_TD_BM), Npad / SA_TD_BN, B);
   hipLaunchKernelGGL(sa_tdnn_fwd_kernel, grid, dim3(256), 0, reinterpret_cast<hipStream_t>(stream), x,
                      reinterpret_cast<const bf16x8*>(wp), bias, bn_s, bn_t, y, T, Cin, Cout, Npad, K, dil,
+                     slope, mask);
+  hipError_t e = hipGetLastError();
+  return e == hipSuccess ? 0 : -(int)e;
+}
+
+// ---------------------------------------------------------------------------------
+// Input gradient of a (frozen, eval-mode) TDNN block  y = BN_eval(LeakyReLU(conv_same_reflect(x)))
+// (models/EndToEnd.py:57-61,81: the pretrained x-vector classifier sits in the training graph
+// with requires_grad off, so only d loss / d x is needed; blocks as in
+// models/external_gender_classifiers.py:71-100).
+//   d z[t][c] = d y[t][c] * bn_s[c] * (z > 0 ? 1 : slope),   z > 0 from the branch mask the forward
+//               wrote (recovering the sign from the stored y = s*leaky(z) + t cancels for small z)
+//   d xe[p]   = sum_k W_k^T d z[p + pad - k*dil]              on the EXTENDED range p in [-pad, T + pad)
+//   d x[j]    = d xe[j] + d xe[-j] (1 <= j <= pad) + d xe[2(T-1) - j] (T-1-pad <= j <= T-2)
+// (the last line is the adjoint of the reflect padding: sa_tdnn_fold).  Same tiling as the forward
+// kernel: 128 rows x 128 output channels per 4-wave workgroup, reduction channels through LDS in
+// chunks of 64 with the tap halo, split-bf16 operands, taps walked in reverse.
+// wp: sa_pack_weights(SA_BF16X3, ...) image of the Conv1d weight as a DATA-GRADIENT operand
+// (reduction = the block's output channels, zero-padded to Cred % 16 == 0; produced = its input
+// channels, zero-padded to Npad % 128 == 0): ntaps = K, K = Cred, N = Npad, sk = Cin_w*K, sn = K, st = 1.
+__global__ __launch_bounds__(256, 2) void sa_tdnn_bwd_kernel(const float* __restrict__ dy,
+                                                              const unsigned char* __restrict__ mask,
+                                                              const float* __restrict__ bn_s,
+                                                              const bf16x8* __restrict__ wp,
+                                                              float* __restrict__ dxe, int T, int Cy,
+                                                              int Cred, int Cin, int Npad, int K, int dil,
+                                                              float slope) {
+  constexpr int PITCH = SA_TD_CK + 8, ROWS = SA_TD_BM + SA_TD_HALO, PLANE = ROWS * PITCH;
+  __shared__ __attribute__((aligned(16))) bf16_t As[2 * PLANE];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wm = wave >> 1, wn = wave & 1;
+  const int t0 = blockIdx.x * SA_TD_BM, n0 = blockIdx.y * SA_TD_BN, b = blockIdx.z;
+  const int pad = dil * (K - 1) / 2, nrows = SA_TD_BM + 2 * pad, Te = T + 2 * pad;
+  const int KSTEPS = Cred / 16, NT = Npad / 32;
+  const size_t lo_off = (size_t)K * KSTEPS * NT * 64;
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) acc[mt][nt][i] = 0.0f;
+  const float* dyb = dy + (size_t)b * T * Cy;
+  const unsigned char* mb = mask + (size_t)b * T * Cy;
+  for (int c0 = 0; c0 < Cred; c0 += SA_TD_CK) {
+    const int ck = Cred - c0 < SA_TD_CK ? Cred - c0 : SA_TD_CK, chunks = ck / 4;
+    // ---- stage d z rows (extended output row t0 + r uses d z[t0 + r - 2*pad + k'*dil]): zero
+    // outside the utterance, LeakyReLU / BatchNorm(eval) backward applied on the fly ----
+    for (int e = tid; e < nrows * chunks; e += 256) {
+      const int r = e / chunks, c = e % chunks, ch = c0 + c * 4;
+      const int tt = t0 + r - 2 * pad;
+      float f[4] = {0.f, 0.f, 0.f, 0.f};
+      if (tt >= 0 && tt < T && ch < Cy) {
+        const float4 g = *reinterpret_cast<const float4*>(dyb + (size_t)tt * Cy + ch);
+        const uchar4 m4 = *reinterpret_cast<const uchar4*>(mb + (size_t)tt * Cy + ch);
+        const float gg[4] = {g.x, g.y, g.z, g.w};
+        const unsigned char mm[4] = {m4.x, m4.y, m4.z, m4.w};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) f[j] = gg[j] * (bn_s ? bn_s[ch + j] : 1.0f) * (mm[j] ? 1.0f : slope);
+      }
+      uint2 hi, lo;
+      sa_split4(f, hi, lo);
+      *reinterpret_cast<uint2*>(As + r * PITCH + c * 4) = hi;
+      *reinterpret_cast<uint2*>(As + PLANE + r * PITCH + c * 4) = lo;
+    }
+    __syncthreads();
+    const int ksteps = ck / 16;
+    for (int k = 0; k < K; ++k) {
+      for (int ks = 0; ks < ksteps; ++ks) {
+        const bf16x8* wt = wp + (((size_t)(K - 1 - k) * KSTEPS + c0 / 16 + ks) * NT + n0 / 32 + wn * 2) * 64 + lane;
+        bf16x8 bh[2], bl[2], ah[2], al[2];
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt) { bh[nt] = wt[nt * 64]; bl[nt] = wt[lo_off + nt * 64]; }
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt) {
+          const bf16_t* ap = As + (wm * 64 + mt * 32 + (lane & 31) + k * dil) * PITCH + ks * 16 + 8 * (lane >> 5);
+          ah[mt] = *reinterpret_cast<const bf16x8*>(ap);
+          al[mt] = *reinterpret_cast<const bf16x8*>(ap + PLANE);
+        }
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+          for (int nt = 0; nt < 2; ++nt) {
+            acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[mt], bh[nt], acc[mt][nt], 0, 0, 0);
+            acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[mt], bl[nt], acc[mt][nt], 0, 0, 0);
+            acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[mt], bh[nt], acc[mt][nt], 0, 0, 0);
+          }
+      }
+    }
+    __syncthreads();
+  }
+#pragma unroll
+  for (int nt = 0; nt < 2; ++nt) {
+    const int n = n0 + (wn * 2 + nt) * 32 + (lane & 31);
+    if (n < Cin) {
+#pragma unroll
+      for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+          const int t = t0 + wm * 64 + mt * 32 + sa_acc_row(i, lane);
+          if (t < Te) dxe[((size_t)b * Te + t) * Cin + n] = acc[mt][nt][i];
+        }
+    }
+  }
+}
+
+// dxe: [B][T + 2*pad][Cin] (pad = dil*(K-1)/2), caller-allocated; feed it to sa_tdnn_fold.
+extern "C" int sa_tdnn_bwd_input(const float* dy, const unsigned char* mask, const float* bn_s,
+                                 const void* wp, float* dxe, int B, int T, int Cy, int Cred, int Cin,
+                                 int Npad, int K, int dil, float slope, void* stream) {
+  if (!dy || !mask || !wp || !dxe || B <= 0 || T <= 0 || Cy <= 0 || Cin <= 0 || K < 1 || !(K & 1) || dil < 1 ||
+      dil * (K - 1) / 2 >= T || dil * (K - 1) > SA_TD_HALO || Cred % 16 || Cred < Cy || Cy % 4 ||
+      Npad % SA_TD_BN || Npad < Cin)
+    return -22;
+  const int Te = T + dil * (K - 1);
+  dim3 grid(sa_div_up(Te, SA_TD_BM), Npad / SA_TD_BN, B);
+  hipLaunchKernelGGL(sa_tdnn_bwd_kernel, grid, dim3(256), 0, reinterpret_cast<hipStream_t>(stream), dy, mask,
+                     bn_s, reinterpret_cast<const bf16x8*>(wp), dxe, T, Cy, Cred, Cin, Npad, K, dil,
                      slope);
+  hipError_t e = hipGetLastError();
+  return e == hipSuccess ? 0 : -(int)e;
+}
+
+// adjoint of the reflect padding: dx[j] = dxe[j + pad] + dxe[pad - j] (1 <= j <= pad)
+//                                       + dxe[2(T-1) - j + pad] (T-1-pad <= j <= T-2)
+__global__ void sa_tdnn_fold_kernel(const float* __restrict__ dxe, float* __restrict__ dx, int T, int C,
+                                    int pad, size_t total) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  const int c = (int)(i % C);
+  const size_t bt = i / C;
+  const int j = (int)(bt % T);
+  const size_t b = bt / T;
+  const float* e = dxe + (b * (size_t)(T + 2 * pad)) * C + c;
+  float v = e[(size_t)(j + pad) * C];
+  if (j >= 1 && j <= pad) v += e[(size_t)(pad - j) * C];
+  if (j >= T - 1 - pad && j <= T - 2) v += e[(size_t)(2 * (T - 1) - j + pad) * C];
+  dx[i] = v;
+}
+
+extern "C" int sa_tdnn_fold(const float* dxe, float* dx, int B, int T, int C, int pad, void* stream) {
+  if (!dxe || !dx || B <= 0 || T <= 0 || C <= 0 || pad < 0 || pad >= T) return -22;
+  const size_t total = (size_t)B * T * C;
+  hipLaunchKernelGGL(sa_tdnn_fold_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0,
+                     reinterpret_cast<hipStream_t>(stream), dxe, dx, T, C, pad, total);
+  hipError_t e = hipGetLastError();
+  return e == hipSuccess ? 0 : -(int)e;
+}
+
+// backward of sa_time_pool (statistics over the first n = round(len*T) frames):
+//   dx[t][c] = g_mean[c]/n + g_std[c] * (x[t][c] - mean[c]) / ((n-1) * std[c])   for t < n, else 0
+// pooled = the forward output [B][2C] WITHOUT the noise offset on the mean half (mean, std + eps).
+__global__ void sa_time_pool_bwd_kernel(const float* __restrict__ x, const float* __restrict__ lens,
+                                        const float* __restrict__ g, const float* __restrict__ pooled,
+                                        int T, int C, float eps, float* __restrict__ dx, size_t total) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  const int c = (int)(i % C);
+  const size_t bt = i / C;
+  const int t = (int)(bt % T);
+  const size_t b = bt / T;
+  int n = lens ? (int)rintf(lens[b] * (float)T) : T;
+  if (n > T) n = T;
+  float v = 0.0f;
+  if (t < n) {
+    const float m = pooled[b * 2 * C + c], sd = pooled[b * 2 * C + C + c] - eps;
+    v = g[b * 2 * C + c] / (float)n;
+    if (n > 1 && sd > 0.0f) v += g[b * 2 * C + C + c] * (x[i] - m) / ((float)(n - 1) * sd);
+  }
+  dx[i] = v;
+}
+
+extern "C" int sa_time_pool_bwd(const float* x, const float* lens, const float* g, const float* pooled,
+                                int B, int T, int C, float eps, float* dx, void* stream) {
+  if (!x || !g || !pooled || !dx || B <= 0 || T <= 0 || C <= 0) return -22;
+  const size_t total = (size_t)B * T * C;
+  hipLaunchKernelGGL(sa_time_pool_bwd_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0,
+                     reinterpret_cast<hipStream_t>(stream), x, lens, g, pooled, T, C, eps, dx, total);
+  hipError_t e = hipGetLastError();
+  return e == hipSuccess ? 0 : -(int)e;
+}
+
+// backward of sa_leaky_affine: dx = dy * s[c] * (x > 0 ? 1 : slope)
+__global__ void sa_leaky_affine_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ x,
+                                           const float* __restrict__ s, float slope, int M, int C, float* dx) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= M * C) return;
+  dx[i] = dy[i] * (s ? s[i % C] : 1.0f) * (x[i] > 0.0f ? 1.0f : slope);
+}
+
+extern "C" int sa_leaky_affine_bwd(const float* dy, const float* x, const float* s, float slope, int M, int C,
+                                   float* dx, void* stream) {
+  if (!dy || !x || !dx) return -22;
+  hipLaunchKernelGGL(sa_leaky_affine_bwd_kernel, dim3(sa_div_up(M * C, 256)), dim3(256), 0,
+                     reinterpret_cast<hipStream_t>(stream), dy, x, s, slope, M, C, dx);
   hipError_t e = hipGetLastError();
   return e == hipSuccess ? 0 : -(int)e;
 }

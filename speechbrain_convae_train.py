@@ -32,9 +32,20 @@ def main(argv):
     if sdist.if_main_process():
         os.makedirs(hparams["output_folder"], exist_ok=True)
 
-    if hparams["model_type"] != "convae":
-        raise SystemExit("this path implements model_type convae (SURVEY.md 8)")
-    model = convae.ConvAutoencoder(precision=hparams.get("precision", "bf16x3"))
+    if hparams["model_type"] == "convae":
+        model = convae.ConvAutoencoder(precision=hparams.get("precision", "bf16x3"))
+    elif hparams["model_type"] == "endtoend":              # reference :551-558 (EndToEnd.ConvReconstruction)
+        from speech_anonymization_amd import endtoend, xvector
+        clf = xvector.EncoderClassifier()
+        ck = hparams.get("external_classifier_ckpt")       # directory with embedding_model.ckpt / classifier.ckpt
+        if ck:
+            clf.embedding_model.load_state_dict(torch.load(os.path.join(ck, "embedding_model.ckpt"),
+                                                           map_location="cpu", weights_only=True))
+            clf.classifier.load_state_dict(torch.load(os.path.join(ck, "classifier.ckpt"),
+                                                      map_location="cpu", weights_only=True))
+        model = endtoend.ConvReconstruction(clf, precision=hparams.get("precision", "bf16x3"))
+    else:
+        raise SystemExit("this path implements model_type convae and endtoend (SURVEY.md 8)")
 
     sa_brain = B.SexAnonymizationTraining(modules=hparams["modules"], opt_class=hparams["Adam"],
                                           hparams=hparams, run_opts=run_opts,

@@ -236,3 +236,49 @@ def test_train_logger_number_format():
     the endtoend sign branch print in scientific notation, as in the reference's train_log.txt)"""
     from speech_anonymization_amd.brain import FileTrainLogger
     assert FileTrainLogger._fmt({"a": 2.5, "b": -2.5, "c": 0.5, "d": 150.0}) == "a: 2.50, b: -2.50e+00, c: 5.00e-01, d: 1.50e+02"
+
+
+def test_similarity_and_accuracy_stats():
+    """utils/utility_similarity_aggregator.py:4-53 and the AccuracyStats calls of
+    speechbrain_convae_train.py:133-149"""
+    from speech_anonymization_amd.metrics import AccuracyStats, SimilarityMetricsStats
+    s = SimilarityMetricsStats()
+    s.append(torch.tensor([0.5, 0.7])); s.append(torch.tensor([0.9]))
+    assert abs(float(s.peek()) - 0.7) < 1e-6 and abs(float(s.summarize()) - 0.7) < 1e-6
+    assert s.denom == 3 and float(s.summary["average"]) == float(s.summarize())
+    a = AccuracyStats()
+    logp = torch.log(torch.tensor([[0.9, 0.1], [0.2, 0.8], [0.6, 0.4]]))
+    lab = torch.tensor([0, 1, 1])
+    a.append(logp.unsqueeze(0), lab.unsqueeze(0), torch.tensor(3).unsqueeze(0))
+    assert abs(a.summarize() - 2 / 3) < 1e-9
+
+
+def test_checkpoint_keep_only_find_and_average(tmp_path):
+    """save_and_keep_only(max_keys=[Utility_Retention], min_keys=[ACC_external], num_to_keep),
+    find_checkpoints(max_key / min_key) and average_checkpoints (speechbrain_convae_train.py:338-343,
+    404-415)"""
+    import time
+    from speech_anonymization_amd.checkpoint import Checkpointer
+    lin = torch.nn.Linear(3, 2)
+    bn = torch.nn.BatchNorm1d(2)
+    model = torch.nn.ModuleList([lin, bn])
+    ck = Checkpointer(str(tmp_path / "save"), {"model": model})
+    vals = [(0.60, 0.50), (0.55, 0.70), (0.65, 0.40), (0.50, 0.60)]      # (ACC_external, Utility_Retention)
+    weights = []
+    for i, (acc, ur) in enumerate(vals):
+        with torch.no_grad():
+            lin.weight.fill_(float(i)); bn.num_batches_tracked.fill_(i)
+        weights.append(float(i))
+        ck.save_and_keep_only(epoch=i, meta={"ACC_external": acc, "Utility_Retention": ur},
+                              max_keys=["Utility_Retention"], min_keys=["ACC_external"], num_to_keep=1)
+        time.sleep(0.01)
+    kept = ck._list()
+    # best Utility_Retention = #1 (0.70), lowest ACC_external = #3 (0.50) which is also the most recent
+    assert len(kept) == 2
+    best_ur = ck.find_checkpoints(max_key="Utility_Retention")
+    best_acc = ck.find_checkpoints(min_key="ACC_external")
+    assert ck._meta(os.path.basename(best_ur[0]))["Utility_Retention"] == 0.70
+    assert ck._meta(os.path.basename(best_acc[0]))["ACC_external"] == 0.50
+    avg = Checkpointer.average_checkpoints(ck.find_checkpoints(), recoverable_name="model")
+    assert torch.allclose(avg["0.weight"], torch.full((2, 3), (1.0 + 3.0) / 2))
+    assert int(avg["1.num_batches_tracked"]) == 2 and avg["1.num_batches_tracked"].dtype == torch.long
