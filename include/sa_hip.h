@@ -27,6 +27,11 @@ extern "C" {
 #define SA_BF16 1
 #define SA_BF16X3 2   /* fp32 storage, split-bf16 operands, 3 bf16 MFMAs per k-step */
 #define SA_BF16X1F 3  /* fp32 storage, operands rounded to bf16 once, 1 bf16 MFMA (sa_wgrad only) */
+#define SA_FP8 4      /* bf16 storage; MFMA operands OCP e4m3: the activation rows are quantised while
+                       * they are staged, the weight image is e4m3 scaled by a per-tensor power of two
+                       * (SaConvArgs.wscale, undone in the epilogue); fp32 accumulation and statistics.
+                       * Forward-type launches of sa_conv_gemm only (BASELINE config 5: "fp8
+                       * weights/activations"); gradients stay on SA_BF16. */
 #define SA_MAX_TAPS 5
 
 /* ---- implicit-GEMM convolution (sa_conv_gemm.hip) -------------------------------------
@@ -82,6 +87,8 @@ typedef struct SaConvArgs {
   /* optional, launches with s1/t1 + swish and no s2: per-tile (sum, sum of squares) of the
    * transformed input rows P(x), [B][ntiles][CIN][2] */
   float* pro_stats;
+  /* SA_FP8: device scalar the e4m3 weight image was multiplied with (accumulators are divided by it) */
+  const float* wscale;
 } SaConvArgs;
 
 int sa_conv_gemm(int dtype, int cin, int cout, int sa, int u, const SaConvArgs* a, void* stream);
@@ -112,8 +119,12 @@ int sa_pack_weights(int dtype, const float* src, void* dst, int ntaps, int K, in
 typedef struct SaPackDesc {
   const float* src; void* dst;
   int dtype, ntaps, K, N, sk, sn, st, pad_;
+  float* scale;          /* SA_FP8 images: device scalar, written by sa_pack_scales_multi, read by the packer */
 } SaPackDesc;
 int sa_pack_weights_multi(const SaPackDesc* descs, int n, int blocks_per_image, void* stream);
+/* per-tensor power-of-two scale of every SA_FP8 image of the table: 2^floor(log2(448 / max|w|))
+ * (one workgroup per image; run it before sa_pack_weights_multi) */
+int sa_pack_scales_multi(const SaPackDesc* descs, int n, void* stream);
 
 /* ---- weight gradients (sa_wgrad.hip) --------------------------------------------------
  * dW[t][ci][co] = sum_b sum_{m<Mrows} P(x)[b, m*SA+off[t], ci] * dy[b, m*U+ph[t], co];

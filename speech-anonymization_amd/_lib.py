@@ -12,7 +12,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # SA_HIP_LIB points the binding at another build of the same ABI (kernel A/B experiments)
 LIB_PATH = os.environ.get("SA_HIP_LIB") or os.path.join(_HERE, "libsa_hip.so")
 
-F32, BF16, BF16X3, BF16X1F = 0, 1, 2, 3
+F32, BF16, BF16X3, BF16X1F, FP8 = 0, 1, 2, 3, 4
 MAX_TAPS = 5
 
 c_fp = C.POINTER(C.c_float)
@@ -35,12 +35,13 @@ class SaConvArgs(C.Structure):
                 ("a_out", vp),
                 ("nb_x", vp), ("nb_c1", vp), ("nb_c2", vp), ("nb_c3", vp),
                 ("nb_bstride", C.c_int), ("nb_relu_mask", C.c_int), ("nb_colsum", vp),
-                ("ep_g2k1", vp), ("ep_g2k2", vp), ("ep_g2k3", vp), ("pro_stats", vp)]
+                ("ep_g2k1", vp), ("ep_g2k2", vp), ("ep_g2k3", vp), ("pro_stats", vp), ("wscale", vp)]
 
 
 class SaPackDesc(C.Structure):
     _fields_ = [("src", vp), ("dst", vp), ("dtype", C.c_int), ("ntaps", C.c_int), ("K", C.c_int),
-                ("N", C.c_int), ("sk", C.c_int), ("sn", C.c_int), ("st", C.c_int), ("pad_", C.c_int)]
+                ("N", C.c_int), ("sk", C.c_int), ("sn", C.c_int), ("st", C.c_int), ("pad_", C.c_int),
+                ("scale", vp)]
 
 
 class SaWgradArgs(C.Structure):
@@ -64,7 +65,7 @@ class SaEwArgs(C.Structure):
 # every symbol include/sa_hip.h declares (checked by tests/test_abi.py on CPU)
 SYMBOLS = [
     "sa_conv_gemm", "sa_abi_sizeof", "sa_conv_gemm_ntiles", "sa_conv_gemm_set_tile_rows",
-    "sa_conv_gemm_geometry", "sa_conv_gemm_set_impl", "sa_conv_pp_set_tile_rows", "sa_pack_weights", "sa_pack_weights_multi", "sa_wgrad", "sa_wgrad_kw", "sa_wgrad_reduce",
+    "sa_conv_gemm_geometry", "sa_conv_gemm_set_impl", "sa_conv_pp_set_tile_rows", "sa_pack_weights", "sa_pack_weights_multi", "sa_pack_scales_multi", "sa_wgrad", "sa_wgrad_kw", "sa_wgrad_reduce",
     "sa_conv1toC", "sa_conv1toC_ntiles", "sa_convCto1", "sa_wgrad1C", "sa_wgrad1C_nchunk",
     "sa_sum_slabs", "sa_ew_stats", "sa_ew_apply", "sa_ew_ntiles", "sa_act_stats",
     "sa_sum_partials", "sa_sum_rows_d", "sa_fin_in_fwd", "sa_fin_bn_fwd", "sa_fin_bn_eval", "sa_fin_norm_bwd", "sa_fin_bias",

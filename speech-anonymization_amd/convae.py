@@ -97,7 +97,7 @@ class ConvAutoencoder(nn.Module):
         self.act_dtype, self.kcode = ops.PRECISIONS[precision]
         # kernel precision of the decoder convolutions (experiment knob, default = same as the rest)
         self.dec_kcode = self.kcode
-        self.dgrad_kcode = self.kcode
+        self.dgrad_kcode = ops.DGRAD_CODE[precision]
         # forward convs also store their transformed input in bf16 for the weight gradient
         # (bf16x3 / bf16x1f models; +1/2 of the saved activations in memory, identical results)
         self.cache_wgrad_operand = cache_wgrad_operand
@@ -279,7 +279,7 @@ class _ConvAEFn(torch.autograd.Function):
         # its weight gradient multiplies with (saves the recomputation and half of the bytes there)
         A = {}
         cache_a = (train and model.cache_wgrad_operand and any(ctx.needs_input_grad)
-                   and ops.WGRAD_CODE[model.precision] in (L.BF16X1F, L.BF16))
+                   and ops.WGRAD_CODE[model.precision] in (L.BF16X1F, L.BF16) and model.kcode != L.FP8)
 
         def cg(x, w, key, *args, **kw):
             if cache_a and key is not None and P[key].requires_grad:

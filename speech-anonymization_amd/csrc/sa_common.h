@@ -116,6 +116,14 @@ struct bf16x3_t {};
 //               further layers, so the split buys nothing there (tools/precision_probe.py).
 struct bf16x1f_t {};
 
+//   SA_FP8    : bf16 storage; LDS operands and the weight image are OCP e4m3 (gfx950's fp8), one
+//               v_mfma_f32_32x32x16_fp8_fp8 per k-step (same rate as bf16), fp32 accumulation.
+//               Activations are quantised as they are staged (they are post-normalisation, O(1):
+//               no scale; values beyond +-448 saturate), the weights carry a per-tensor power-of-two
+//               scale that the epilogue divides out.  Forward launches only.
+struct fp8_t {};
+typedef long fp8x8;                       // 8 e4m3 values: one MFMA operand fragment
+
 template <typename T> struct Pol;
 template <> struct Pol<float> {
   typedef float store_t; typedef float lds_t; typedef float Frag;
@@ -133,6 +141,28 @@ template <> struct Pol<bf16x3_t> {
   typedef float store_t; typedef bf16_t lds_t; typedef bf16x8 Frag;
   static constexpr int NPL = 2, VEC = 4, KS = 16, PAD = 8;
 };
+
+template <> struct Pol<fp8_t> {
+  typedef bf16_t store_t; typedef unsigned char lds_t; typedef fp8x8 Frag;
+  static constexpr int NPL = 1, VEC = 8, KS = 16, PAD = 8;      // pitch = C + 8 bytes: conflict-free ds_read_b64
+};
+template <> struct Tr<unsigned char> {
+  __device__ static inline f32x16 mfma(fp8x8 a, fp8x8 b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_fp8_fp8(a, b, c, 0, 0, 0);
+  }
+};
+// 8 floats -> 8 e4m3 (v_cvt_pk_fp8_f32, RNE; clamped to the finite range first)
+__device__ static inline uint2 sa_pack_fp8x8(const float* f) {
+  float c[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) c[j] = __builtin_amdgcn_fmed3f(f[j], -448.0f, 448.0f);
+  int lo = 0, hi = 0;
+  lo = __builtin_amdgcn_cvt_pk_fp8_f32(c[0], c[1], lo, false);
+  lo = __builtin_amdgcn_cvt_pk_fp8_f32(c[2], c[3], lo, true);
+  hi = __builtin_amdgcn_cvt_pk_fp8_f32(c[4], c[5], hi, false);
+  hi = __builtin_amdgcn_cvt_pk_fp8_f32(c[6], c[7], hi, true);
+  return make_uint2((unsigned)lo, (unsigned)hi);
+}
 
 __device__ static inline uint2 sa_pack_bf16x4(const float* f) {
   return make_uint2(sa_pack_bf16x2(f[0], f[1]), sa_pack_bf16x2(f[2], f[3]));

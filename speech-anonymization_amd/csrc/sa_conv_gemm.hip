@@ -144,6 +144,8 @@ __global__ __launch_bounds__(256, 2) void sa_conv_gemm_kernel(SaConvArgs a, int 
             sa_split4(f, hi, lo);
             *reinterpret_cast<uint2*>(dst) = hi;
             *reinterpret_cast<uint2*>(dst + plane) = lo;
+          } else if constexpr (sizeof(LT) == 1) {
+            *reinterpret_cast<uint2*>(dst) = sa_pack_fp8x8(f);
           } else if constexpr (sizeof(LT) == 2 && sizeof(S) == 4) {
             *reinterpret_cast<uint2*>(dst) = sa_pack_bf16x4(f);
           } else if constexpr (sizeof(LT) == 2) {
@@ -365,12 +367,14 @@ __global__ __launch_bounds__(256, 2) void sa_conv_gemm_kernel(SaConvArgs a, int 
     const int ph = vt / C::NT, nt = vt % C::NT;
     const int col = nt * 32 + (lane & 31);
     const float bv = a.bias ? a.bias[col] : 0.0f;
+    float winv = 1.0f;                                  // SA_FP8: undo the weight image's scale
+    if constexpr (sizeof(LT) == 1) winv = a.wscale ? 1.0f / a.wscale[0] : 1.0f;
 #pragma unroll
     for (int mt = 0; mt < C::MT; ++mt) {
 #pragma unroll
       for (int i = 0; i < 16; ++i) {
         const int m = wm * C::MT * 32 + mt * 32 + sa_acc_row(i, lane);
-        float val = acc[v][mt][i] + bv;
+        float val = sizeof(LT) == 1 ? fmaf(acc[v][mt][i], winv, bv) : acc[v][mt][i] + bv;
         if (a.relu) val = fmaxf(val, 0.0f);
         Os[(size_t)(m * U + ph) * C::OPITCH + col] = tr::from_f(val);
       }
@@ -589,6 +593,7 @@ static int launch_tm(const SaConvArgs& a, hipStream_t st) {
     if (a->nb_x)                                                                 \
       return dtype == SA_BF16X3 ? launch_tm<bf16x3_t, CI, CO, S, UU, true>(*a, st) \
              : dtype == SA_BF16 ? launch_tm<bf16_t, CI, CO, S, UU, true>(*a, st) : -22; \
+    if (dtype == SA_FP8) return (a->wscale && !a->ep_mode) ? launch_tm<fp8_t, CI, CO, S, UU>(*a, st) : -22; \
     return dtype == SA_BF16 ? launch_tm<bf16_t, CI, CO, S, UU>(*a, st)           \
            : dtype == SA_BF16X3 ? launch_tm<bf16x3_t, CI, CO, S, UU>(*a, st)     \
            : dtype == SA_BF16X1F ? launch_tm<bf16x1f_t, CI, CO, S, UU>(*a, st)   \

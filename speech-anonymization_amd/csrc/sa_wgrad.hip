@@ -70,13 +70,96 @@ __global__ void sa_pack_weights_split_kernel(const float* __restrict__ src, bf16
   }
 }
 
+// ---- SA_FP8 images: e4m3 fragments (8 per lane, same k order as the bf16 image) of w * scale,
+// scale = 2^floor(log2(448 / max|w|)) per tensor, stored as a float right behind the image
+// (byte offset ntaps*K*N, a multiple of 512)
+__device__ static inline float sa_pow2_scale(float amax) {
+  if (!(amax > 0.0f) || !(amax < 3.0e38f)) return 1.0f;
+  return exp2f(floorf(log2f(448.0f / amax)));
+}
+
+__global__ void sa_pack_scale_kernel(const float* __restrict__ src, float* __restrict__ scale, int ntaps,
+                                     int K, int N, int sk, int sn, int st) {
+  __shared__ float red[256];
+  float m = 0.0f;
+  const int total = ntaps * K * N;
+  for (int i = threadIdx.x; i < total; i += blockDim.x) {
+    const int n = i % N, k = (i / N) % K, t = i / (N * K);
+    m = fmaxf(m, fabsf(src[(size_t)k * sk + (size_t)n * sn + (size_t)t * st]));
+  }
+  red[threadIdx.x] = m;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if ((int)threadIdx.x < o) red[threadIdx.x] = fmaxf(red[threadIdx.x], red[threadIdx.x + o]);
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) scale[0] = sa_pow2_scale(red[0]);
+}
+
+__device__ static inline unsigned char sa_to_fp8(float v) {
+  v = __builtin_amdgcn_fmed3f(v, -448.0f, 448.0f);
+  return (unsigned char)(__builtin_amdgcn_cvt_pk_fp8_f32(v, 0.0f, 0, false) & 0xff);
+}
+
+__global__ void sa_pack_weights_fp8_kernel(const float* __restrict__ src, unsigned char* __restrict__ dst,
+                                           const float* __restrict__ scale, int ntaps, int K, int N,
+                                           int sk, int sn, int st) {
+  constexpr int KS = 16, PER = 8;
+  const int total = ntaps * K * N;
+  const int NT = N / 32, KSTEPS = K / KS;
+  const float sc = scale[0];
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+    const int j = i % PER;
+    int r = i / PER;
+    const int lane = r % 64; r /= 64;
+    const int nt = r % NT; r /= NT;
+    const int ks = r % KSTEPS;
+    const int t = r / KSTEPS;
+    const int k = ks * KS + PER * (lane >> 5) + j;
+    const int n = nt * 32 + (lane & 31);
+    dst[i] = sa_to_fp8(src[(size_t)k * sk + (size_t)n * sn + (size_t)t * st] * sc);
+  }
+}
+
+__global__ void sa_pack_scales_multi_kernel(const SaPackDesc* __restrict__ descs) {
+  const SaPackDesc d = descs[blockIdx.x];
+  if (d.dtype != SA_FP8 || !d.scale) return;
+  __shared__ float red[256];
+  float m = 0.0f;
+  const int total = d.ntaps * d.K * d.N;
+  for (int i = threadIdx.x; i < total; i += blockDim.x) {
+    const int n = i % d.N, k = (i / d.N) % d.K, t = i / (d.N * d.K);
+    m = fmaxf(m, fabsf(d.src[(size_t)k * d.sk + (size_t)n * d.sn + (size_t)t * d.st]));
+  }
+  red[threadIdx.x] = m;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if ((int)threadIdx.x < o) red[threadIdx.x] = fmaxf(red[threadIdx.x], red[threadIdx.x + o]);
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) d.scale[0] = sa_pow2_scale(red[0]);
+}
+
+extern "C" int sa_pack_scales_multi(const SaPackDesc* descs, int n, void* stream) {
+  if (!descs || n <= 0) return -22;
+  hipLaunchKernelGGL(sa_pack_scales_multi_kernel, dim3(n), dim3(256), 0,
+                     reinterpret_cast<hipStream_t>(stream), descs);
+  hipError_t e = hipGetLastError();
+  return e == hipSuccess ? 0 : -(int)e;
+}
+
 extern "C" int sa_pack_weights(int dtype, const float* src, void* dst, int ntaps, int K, int N,
                                int sk, int sn, int st, void* stream) {
   if (!src || !dst || K % 16 || N % 32) return -22;
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   const int total = ntaps * K * N;
   const int grid = sa_div_up(total, 256) < 1024 ? sa_div_up(total, 256) : 1024;
-  if (dtype == SA_BF16 || dtype == SA_BF16X1F)
+  if (dtype == SA_FP8) {
+    float* scale = reinterpret_cast<float*>(reinterpret_cast<unsigned char*>(dst) + total);
+    hipLaunchKernelGGL(sa_pack_scale_kernel, dim3(1), dim3(256), 0, s, src, scale, ntaps, K, N, sk, sn, st);
+    hipLaunchKernelGGL(sa_pack_weights_fp8_kernel, dim3(grid), dim3(256), 0, s, src,
+                       reinterpret_cast<unsigned char*>(dst), scale, ntaps, K, N, sk, sn, st);
+  } else if (dtype == SA_BF16 || dtype == SA_BF16X1F)
     hipLaunchKernelGGL(sa_pack_weights_kernel<bf16_t>, dim3(grid), dim3(256), 0, s, src,
                        reinterpret_cast<bf16_t*>(dst), ntaps, K, N, sk, sn, st);
   else if (dtype == SA_BF16X3)
@@ -107,7 +190,9 @@ __global__ void sa_pack_weights_multi_kernel(const SaPackDesc* __restrict__ desc
     const int k = ks * KS + PER * (lane >> 5) + j;
     const int n = nt * 32 + (lane & 31);
     const float w = d.src[(size_t)k * d.sk + (size_t)n * d.sn + (size_t)t * d.st];
-    if (f32) {
+    if (d.dtype == SA_FP8) {
+      reinterpret_cast<unsigned char*>(d.dst)[i] = sa_to_fp8(w * d.scale[0]);
+    } else if (f32) {
       reinterpret_cast<float*>(d.dst)[i] = w;
     } else {
       bf16_t* o = reinterpret_cast<bf16_t*>(d.dst);

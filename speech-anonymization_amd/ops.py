@@ -76,9 +76,14 @@ PROFILE = _Profile()
 
 # precision modes of the MFMA kernels: name -> (activation storage dtype, kernel dtype code)
 PRECISIONS = {"f32": (torch.float32, L.F32), "bf16": (torch.bfloat16, L.BF16),
-              "bf16x3": (torch.float32, L.BF16X3), "bf16x1f": (torch.float32, L.BF16X1F)}
+              "bf16x3": (torch.float32, L.BF16X3), "bf16x1f": (torch.float32, L.BF16X1F),
+              # fp8: bf16 storage, OCP e4m3 MFMA operands (weights + activations) in the forward
+              # convolutions; gradients on the bf16 kernels (BASELINE config 5)
+              "fp8": (torch.bfloat16, L.FP8)}
 # kernel code of the weight-gradient GEMM per model precision (SA_BF16X1F: see sa_common.h)
-WGRAD_CODE = {"f32": L.F32, "bf16": L.BF16, "bf16x3": L.BF16X1F, "bf16x1f": L.BF16X1F}
+WGRAD_CODE = {"f32": L.F32, "bf16": L.BF16, "bf16x3": L.BF16X1F, "bf16x1f": L.BF16X1F, "fp8": L.BF16}
+# kernel code of the data-gradient convolutions per model precision
+DGRAD_CODE = {"f32": L.F32, "bf16": L.BF16, "bf16x3": L.BF16X3, "bf16x1f": L.BF16X1F, "fp8": L.BF16}
 
 
 def _pack_geometry(shape, kind):
@@ -95,6 +100,8 @@ def _pack_geometry(shape, kind):
 
 
 def _image_buffer(code, dtype, n, device):
+    if code == L.FP8:                       # e4m3 image + its per-tensor scale (a float) behind it
+        return torch.empty(n + 4, dtype=torch.uint8, device=device)
     if code == L.BF16X3:
         return torch.empty(2 * n, dtype=torch.bfloat16, device=device)
     if code in (L.BF16X1F, L.BF16):
@@ -129,12 +136,16 @@ class PackedWeights:
             self.images[tag] = (img, code)
             d.src, d.dst, d.dtype = w.data_ptr(), img.data_ptr(), code
             d.ntaps, d.K, d.N, d.sk, d.sn, d.st = Kw, K, N, sk, sn, 1
+            d.scale = img.data_ptr() + Kw * K * N if code == L.FP8 else None
+            self.fp8 = getattr(self, "fp8", False) or code == L.FP8
         raw = torch.frombuffer(bytearray(bytes(descs)), dtype=torch.uint8)
         self.table = raw.to(dev)
         self.n = len(items)
         self.key = tuple(w.data_ptr() for _, w, _, _ in items)
 
     def refresh(self):
+        if getattr(self, "fp8", False):     # per-tensor scales of the e4m3 images first
+            L.check(L.load().sa_pack_scales_multi(_f(self.table), self.n, L.stream()), "sa_pack_scales_multi")
         L.check(L.load().sa_pack_weights_multi(_f(self.table), self.n, 64, L.stream()),
                 "sa_pack_weights_multi")
 
@@ -183,6 +194,8 @@ def conv_gemm(x, wp, bias, cin, cout, sa, u, phases, Lout, s1=None, t1=None, s2=
     a.swish, a.relu, a.stats = int(swish), int(relu), _f(stats)
     a.B, a.Lin, a.Lout = B, Lin, Lout
     a.taps = L.make_taps(phases)
+    if kc == L.FP8:                          # the scale sits behind the e4m3 image
+        a.wscale = C.c_void_p(wp.data_ptr() + wp.numel() - 4)
     if a_out is not None:
         assert a_out.dtype == torch.bfloat16 and a_out.shape == x.shape
         a.a_out = _f(a_out)

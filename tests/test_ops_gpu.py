@@ -647,3 +647,70 @@ def test_pingpong_conv_kernel_in_the_model():
     for k, g in out[0][2].items():
         if k not in NULL_BIAS:
             assert rel_mse(out[1][2][k], g) < 1e-5, k       # classifier branch amplifies the slab-order noise
+
+
+def _fp8_e4m3(t):
+    """OCP e4m3 round trip (saturating), the quantisation of the SA_FP8 operand path"""
+    return t.clamp(-448.0, 448.0).to(torch.float8_e4m3fn).float()
+
+
+@pytest.mark.parametrize("layer", LAYERS, ids=[l[0] for l in LAYERS])
+def test_conv_forward_fp8_operands(layer):
+    """SA_FP8 (BASELINE config 5): bf16 storage, e4m3 MFMA operands.  Against F.conv1d on operands
+    quantised the same way on the CPU (activations after the prologue transform, weights times their
+    per-tensor power-of-two scale): the products are then exact in fp32, so the kernel must match to
+    the rounding of its bf16 output -- which also pins the e4m3 fragment layout of
+    v_mfma_f32_32x32x16_fp8_fp8."""
+    from speech_anonymization_amd import _lib as L, ops
+    name, cin, cout, K, stride, dil, pad, tr = layer
+    B, Lin = 2, 333
+    x = rnd(torch.bfloat16, B, cin, Lin, seed=1)
+    wshape = (cin, cout, K) if tr else (cout, cin, K)
+    w = rnd(torch.float32, *wshape, seed=2, scale=(cin * K) ** -0.5)
+    bias = rnd(torch.float32, cout, seed=3, scale=0.1)
+    s1, t1 = 1 + 0.2 * rnd(torch.float32, B, cin, seed=7), 0.3 * rnd(torch.float32, B, cin, seed=8)
+    z = x * s1[:, :, None] + t1[:, :, None]
+    a = _fp8_e4m3(z * torch.sigmoid(z))
+    scale = 2.0 ** torch.floor(torch.log2(448.0 / w.abs().max()))
+    wq = _fp8_e4m3(w * scale) / scale
+    y = ref_fwd(a, wq, bias, stride, dil, pad, tr)
+    Lout = y.shape[2]
+    xd, wd = cl(x, torch.bfloat16), w.to(dev())
+    kind = "convT_fwd" if tr else "conv_fwd"
+    wp = ops.pack_weights(wd, kind, torch.bfloat16, L.FP8)
+    args = (cin, cout, 1, 2, ops.UP2, Lout) if tr else (cin, cout, stride, 1, ops.taps_conv(K, dil, pad), Lout)
+    yd, st = ops.conv_gemm(xd, wp, bias.to(dev()), *args, s1=s1.to(dev()), t1=t1.to(dev()), swish=True,
+                           want_stats=True, code=L.FP8)
+    torch.cuda.synchronize()
+    assert abs(float(wp[-4:].view(torch.float32)) - float(scale)) == 0.0       # the scale behind the image
+    assert rel_mse(uncl(yd), y) < 1e-5, name
+    s = ops.sum_partials(st, B).view(B, cout, 2).cpu()
+    yy = yd.double().cpu()
+    assert torch.allclose(s[..., 0], yy.sum(dim=1), rtol=1e-3, atol=1e-2)
+
+
+def test_model_fp8_precision_report():
+    """precision="fp8" end to end (forward convolutions on e4m3 operands, gradients on the bf16
+    kernels): what it costs against the fp32 oracle, next to the bf16 mode on the same input.  The
+    numbers are printed and held to loose bounds: e4m3 has 3 mantissa bits, this mode is a
+    throughput / memory point (BASELINE config 5), not a parity mode."""
+    from oracle.convae import numpy_params
+    from oracle.features import synthetic_feats
+    from tests.test_convae_gpu import run_oracle, run_hip, hip_model, cosine
+    B, T = 4, 144
+    feats = synthetic_feats(B, T, seed=31)
+    target = feats + 0.1 * torch.randn(B, T, 80, generator=torch.Generator().manual_seed(1))
+    gender = torch.arange(B) % 2
+    params = numpy_params(8886)
+    o_recon, o_logp, o_loss, o_grads, _ = run_oracle(params, feats, target, gender, "l1")
+    rows = {}
+    for prec in ("bf16", "fp8"):
+        m = hip_model(prec, params)
+        recon, logp, loss, grads = run_hip(m, feats, target, gender, "l1")
+        rows[prec] = dict(recon=rel_mse(recon.float(), o_recon), loss=abs(loss - o_loss),
+                          dec=rel_mse(grads["decoder.4.weight"], o_grads["decoder.4.weight"]),
+                          dec_cos=cosine(grads["decoder.4.weight"], o_grads["decoder.4.weight"]),
+                          enc_cos=cosine(grads["encoder.5.weight"], o_grads["encoder.5.weight"]))
+        print(prec, {k: f"{v:.3e}" for k, v in rows[prec].items()})
+    assert rows["fp8"]["recon"] < 5e-2 and rows["fp8"]["dec_cos"] > 0.9
+    assert rows["bf16"]["recon"] < 1e-3
