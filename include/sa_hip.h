@@ -92,7 +92,7 @@ typedef struct SaConvArgs {
 } SaConvArgs;
 
 int sa_conv_gemm(int dtype, int cin, int cout, int sa, int u, const SaConvArgs* a, void* stream);
-/* sizeof(SaConvArgs | SaWgradArgs | SaEwArgs | SaPackDesc | SaTaps) for which = 0..4: lets a binding
+/* sizeof(SaConvArgs | SaWgradArgs | SaEwArgs | SaPackDesc | SaTaps | SaFinArgs) for which = 0..5: lets a binding
  * verify its mirror of these records (the library reads every field) */
 int sa_abi_sizeof(int which);
 int sa_conv_gemm_ntiles(int cin, int cout, int u, int Lout);
@@ -203,6 +203,34 @@ int sa_fin_norm_bwd(const double* sums, const double* lsums, int R, int groups, 
                     float* c2, float* c3, float* dgamma, float* dbeta, const double* n_dev,
                     void* stream);
 int sa_fin_bias(const double* sums, int B, int C, int ncomp, float* db, void* stream);  /* sums [B][C][ncomp] */
+
+/* Slab reduction + the finaliser that consumes it in one launch (replaces sa_sum_partials ->
+ * [sa_sum_rows_d ->] sa_fin_* chains; same fp64 sums in the same order, bit-identical results).
+ * part [nbatch][nslab][n] fp32 slabs, n = C * ncomp; rows [nbatch][n] fp64 (written; required except
+ * for SA_FIN_IN_FWD); tickets: >= ceil(n/32) zero-initialised uint32 (self-resetting; one buffer may
+ * serve consecutive launches on one stream).  Modes:
+ *   SA_FIN_IN_FWD  per (b,c): o0..o3 = mean, rstd, scale, shift [nbatch][C]          (count = L)
+ *   SA_FIN_IN_BWD  per (b,c): o0..o2 = c1, c2, c3 [nbatch][C]; dgamma/dbeta [C] = sums over b
+ *   SA_FIN_BN_FWD  sums over the nbatch rows: o0..o3 [C], running statistics        (count = B*L)
+ *   SA_FIN_BN_BWD  sums over the rows: o0..o2 = c1, c2, c3 [C], dgamma/dbeta [C]
+ *   SA_FIN_BIAS    db[c] = sum over rows of component 0 (ncomp 1 or 2)
+ * Single-process statistics only: when sums are all-reduced across ranks (SyncBatchNorm) use the
+ * separate launches. */
+#define SA_FIN_IN_FWD 1
+#define SA_FIN_IN_BWD 2
+#define SA_FIN_BN_FWD 3
+#define SA_FIN_BN_BWD 4
+#define SA_FIN_BIAS 5
+typedef struct SaFinArgs {
+  const float* part; double* rows; unsigned int* tickets;
+  int nbatch, nslab, n, C, ncomp, mode;
+  double count;
+  float eps, momentum, sign, pad_;
+  const float* gamma; const float* beta; const float* mean; const float* rstd;
+  float* o0; float* o1; float* o2; float* o3;
+  float* dgamma; float* dbeta; float* db; float* run_mean; float* run_var;
+} SaFinArgs;
+int sa_reduce_finalize(const SaFinArgs* a, void* stream);
 
 /* ---- classifier head + losses (sa_head.hip): TDNNSexClassifier.forward reshape + pooling
  * (models/ConvAutoEncoder.py:61-66), classify (:47-55), log_softmax (:68); losses at

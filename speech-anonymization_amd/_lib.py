@@ -62,13 +62,25 @@ class SaEwArgs(C.Structure):
                 ("B", C.c_int), ("L", C.c_int), ("ntiles", C.c_int)]
 
 
+class SaFinArgs(C.Structure):
+    _fields_ = [("part", vp), ("rows", vp), ("tickets", vp),
+                ("nbatch", C.c_int), ("nslab", C.c_int), ("n", C.c_int), ("C", C.c_int), ("ncomp", C.c_int),
+                ("mode", C.c_int), ("count", C.c_double),
+                ("eps", C.c_float), ("momentum", C.c_float), ("sign", C.c_float), ("pad_", C.c_float),
+                ("gamma", vp), ("beta", vp), ("mean", vp), ("rstd", vp),
+                ("o0", vp), ("o1", vp), ("o2", vp), ("o3", vp),
+                ("dgamma", vp), ("dbeta", vp), ("db", vp), ("run_mean", vp), ("run_var", vp)]
+
+
+FIN_IN_FWD, FIN_IN_BWD, FIN_BN_FWD, FIN_BN_BWD, FIN_BIAS = 1, 2, 3, 4, 5
+
 # every symbol include/sa_hip.h declares (checked by tests/test_abi.py on CPU)
 SYMBOLS = [
     "sa_conv_gemm", "sa_abi_sizeof", "sa_conv_gemm_ntiles", "sa_conv_gemm_set_tile_rows",
     "sa_conv_gemm_geometry", "sa_conv_gemm_set_impl", "sa_conv_pp_set_tile_rows", "sa_pack_weights", "sa_pack_weights_multi", "sa_pack_scales_multi", "sa_wgrad", "sa_wgrad_kw", "sa_wgrad_reduce",
     "sa_conv1toC", "sa_conv1toC_ntiles", "sa_convCto1", "sa_wgrad1C", "sa_wgrad1C_nchunk",
     "sa_sum_slabs", "sa_ew_stats", "sa_ew_apply", "sa_ew_ntiles", "sa_act_stats",
-    "sa_sum_partials", "sa_sum_rows_d", "sa_fin_in_fwd", "sa_fin_bn_fwd", "sa_fin_bn_eval", "sa_fin_norm_bwd", "sa_fin_bias",
+    "sa_sum_partials", "sa_sum_rows_d", "sa_reduce_finalize", "sa_fin_in_fwd", "sa_fin_bn_fwd", "sa_fin_bn_eval", "sa_fin_norm_bwd", "sa_fin_bias",
     "sa_pool_fwd", "sa_pool_nseg", "sa_pool_gather", "sa_pool_fin", "sa_pool_bwd", "sa_dense", "sa_colsums",
     "sa_bn2d_bwd", "sa_dense_wgrad", "sa_log_softmax", "sa_log_softmax_bwd",
     "sa_loss_workspace_bytes", "sa_recon_loss", "sa_cls_losses", "sa_cosine_loss",
@@ -94,7 +106,7 @@ def load():
         _lib = C.CDLL(LIB_PATH)
         for s in SYMBOLS:
             getattr(_lib, s).restype = C.c_int
-        for i, rec in enumerate((SaConvArgs, SaWgradArgs, SaEwArgs, SaPackDesc, SaTaps)):
+        for i, rec in enumerate((SaConvArgs, SaWgradArgs, SaEwArgs, SaPackDesc, SaTaps, SaFinArgs)):
             if _lib.sa_abi_sizeof(i) != C.sizeof(rec):
                 raise SaHipError(f"{rec.__name__}: binding has {C.sizeof(rec)} bytes, {LIB_PATH} "
                                  f"{_lib.sa_abi_sizeof(i)} -- rebuild the library (stale build?)")

@@ -608,6 +608,7 @@ extern "C" int sa_abi_sizeof(int which) {
     case 2: return (int)sizeof(SaEwArgs);
     case 3: return (int)sizeof(SaPackDesc);
     case 4: return (int)sizeof(SaTaps);
+    case 5: return (int)sizeof(SaFinArgs);
     default: return -22;
   }
 }

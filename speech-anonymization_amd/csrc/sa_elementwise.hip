@@ -415,3 +415,144 @@ extern "C" int sa_fin_bias(const double* sums, int B, int C, int ncomp, float* d
   hipError_t e = hipGetLastError();
   return e == hipSuccess ? 0 : -(int)e;
 }
+
+// ---------------------------------------------------------------------------------
+// sa_reduce_finalize: slab reduction AND the finaliser that consumes it in ONE launch.
+//
+// The statistics of a convolution come out of its epilogue as per-tile partial slabs; until
+// round 2 every use was two or three tiny launches (sa_sum_partials -> [sa_sum_rows_d ->] sa_fin_*),
+// ~70 per train step.  Here workgroup (chunk j, utterance b) sums its 32 outputs over the slabs
+// exactly like sa_sum_partials (lane q adds slabs q, q+16, ... in order, the 16 lane sums are added
+// in lane order: bit-identical sums), writes them to rows[b][.] (fp64) and
+//   * SA_FIN_IN_FWD : finalises its own 16 channels (InstanceNorm forward is per utterance);
+//   * the modes that need a sum over utterances (BatchNorm forward / backward, d gamma / d beta of
+//     InstanceNorm, bias gradients) take a ticket per chunk; the LAST workgroup of a chunk to arrive
+//     adds the B rows in utterance order (fixed order: deterministic) and runs the finaliser for
+//     its channels.  Hand-off per cdna_hip_programming.md Guideline 16: stores -> vmcnt(0) ->
+//     barrier -> agent-scope release -> vmcnt(0) -> relaxed agent-scope ticket; the last arriver:
+//     agent-scope acquire -> vmcnt(0) -> barrier -> plain loads.  The ticket resets itself.
+// Not used when the sums must be all-reduced first (SyncBatchNorm under DDP): that path keeps
+// the separate launches.
+// ---------------------------------------------------------------------------------
+__global__ __launch_bounds__(32 * SA_SP_LANES) void sa_reduce_finalize_kernel(SaFinArgs a) {
+  __shared__ double part[SA_SP_LANES][33];
+  __shared__ double fin[32];
+  __shared__ int is_last;
+  const int bb = blockIdx.y, o = threadIdx.x & 31, q = threadIdx.x >> 5;
+  const int i = blockIdx.x * 32 + o, n = a.n;
+  double s = 0.0;
+  if (i < n) {
+    const float* p = a.part + (size_t)bb * a.nslab * n + i;
+#pragma unroll 16
+    for (int k = q; k < a.nslab; k += SA_SP_LANES) s += (double)p[(size_t)k * n];
+  }
+  part[q][o] = s;
+  __syncthreads();
+  if (q == 0) {
+    double t = 0.0;
+#pragma unroll
+    for (int r = 0; r < SA_SP_LANES; ++r) t += part[r][o];
+    fin[o] = t;
+    if (i < n && a.rows) a.rows[(size_t)bb * n + i] = t;
+  }
+  const int C = a.C, nc = a.ncomp;
+  if (a.mode == SA_FIN_IN_FWD || a.mode == SA_FIN_IN_BWD) {
+    __syncthreads();
+    // per (utterance, channel): this workgroup holds (S, Q) / (S1, S2) of its 16 channels
+    if (q == 0 && (o & 1) == 0 && i < n) {
+      const int c = i >> 1, g = bb * C + c;
+      if (a.mode == SA_FIN_IN_FWD) {
+        const double m = fin[o] / a.count;
+        double var = fin[o + 1] / a.count - m * m;
+        if (var < 0.0) var = 0.0;
+        const float r = (float)(1.0 / sqrt(var + (double)a.eps));
+        const float sc = a.gamma[c] * r;
+        a.o0[g] = (float)m; a.o1[g] = r; a.o2[g] = sc; a.o3[g] = a.beta[c] - (float)m * sc;
+      } else {
+        const double S1 = fin[o], S2 = fin[o + 1];
+        const double r = a.rstd[g], m = a.mean[g];
+        const double k1 = (double)a.gamma[c] * r;
+        a.o0[g] = a.sign * (float)k1;
+        a.o1[g] = a.sign * (float)(-k1 * r * S2 / a.count);
+        a.o2[g] = a.sign * (float)(k1 * (-S1 / a.count + m * r * S2 / a.count));
+      }
+    }
+    if (a.mode == SA_FIN_IN_FWD) return;
+  }
+  // ---- cross-utterance stage: publish the row, take a ticket, the last arriver finalises ----
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const unsigned old = __hip_atomic_fetch_add(&a.tickets[blockIdx.x], 1u, __ATOMIC_RELAXED,
+                                                __HIP_MEMORY_SCOPE_AGENT);
+    const int last = old == (unsigned)(gridDim.y - 1);
+    if (last) {
+      __hip_atomic_store(&a.tickets[blockIdx.x], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    is_last = last;
+  }
+  __syncthreads();
+  if (!is_last || q != 0 || i >= n) return;
+  double tot = 0.0;                                   // sum over utterances, in utterance order
+  const int B = gridDim.y;
+#pragma unroll 8
+  for (int b = 0; b < B; ++b) tot += a.rows[(size_t)b * n + i];
+  fin[o] = tot;
+  // the 32 finishing lanes are one half-wave: no barrier needed between writing fin[] and reading
+  // the neighbour's entry, but the compiler must not reorder the LDS accesses
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+  __builtin_amdgcn_wave_barrier();
+  const int c = i / nc, comp = i % nc;
+  if (a.mode == SA_FIN_IN_BWD) {                      // d beta = sum_b S1, d gamma = sum_b S2
+    if (a.dgamma) { if (comp == 0) a.dbeta[c] = (float)tot; else a.dgamma[c] = (float)tot; }
+  } else if (a.mode == SA_FIN_BIAS) {
+    if (comp == 0) a.db[c] = (float)tot;
+  } else if (comp == 0) {
+    const double S = fin[o], Q = fin[o + 1];
+    if (a.mode == SA_FIN_BN_FWD) {
+      const double m = S / a.count;
+      double var = Q / a.count - m * m;
+      if (var < 0.0) var = 0.0;
+      const float r = (float)(1.0 / sqrt(var + (double)a.eps));
+      const float sc = a.gamma[c] * r;
+      a.o0[c] = (float)m; a.o1[c] = r; a.o2[c] = sc; a.o3[c] = a.beta[c] - (float)m * sc;
+      if (a.run_mean) {
+        const double unb = a.count > 1.0 ? var * a.count / (a.count - 1.0) : var;
+        a.run_mean[c] = (1.0f - a.momentum) * a.run_mean[c] + a.momentum * (float)m;
+        a.run_var[c] = (1.0f - a.momentum) * a.run_var[c] + a.momentum * (float)unb;
+      }
+    } else {                                          // SA_FIN_BN_BWD: S = S1, Q = S2
+      const double r = a.rstd[c], m = a.mean[c];
+      const double k1 = (double)a.gamma[c] * r;
+      a.o0[c] = a.sign * (float)k1;
+      a.o1[c] = a.sign * (float)(-k1 * r * Q / a.count);
+      a.o2[c] = a.sign * (float)(k1 * (-S / a.count + m * r * Q / a.count));
+      if (a.dgamma) { a.dbeta[c] = (float)S; a.dgamma[c] = (float)Q; }
+    }
+  }
+}
+
+extern "C" int sa_reduce_finalize(const SaFinArgs* a, void* stream) {
+  if (!a || !a->part || a->nbatch <= 0 || a->nslab <= 0 || a->n <= 0 || a->C <= 0 || a->ncomp < 1 ||
+      a->n != a->C * a->ncomp)
+    return -22;
+  const int m = a->mode;
+  if (m < SA_FIN_IN_FWD || m > SA_FIN_BIAS) return -22;
+  if (m != SA_FIN_BIAS && a->ncomp != 2) return -22;
+  if (m != SA_FIN_IN_FWD && (!a->tickets || !a->rows)) return -22;
+  if ((m == SA_FIN_IN_FWD || m == SA_FIN_BN_FWD) && (!a->gamma || !a->beta || !a->o0 || !a->o1 || !a->o2 || !a->o3))
+    return -22;
+  if ((m == SA_FIN_IN_BWD || m == SA_FIN_BN_BWD) && (!a->gamma || !a->mean || !a->rstd || !a->o0 || !a->o1 || !a->o2))
+    return -22;
+  if ((a->dgamma == nullptr) != (a->dbeta == nullptr)) return -22;
+  if (m == SA_FIN_BIAS && !a->db) return -22;
+  if (m != SA_FIN_BIAS && !(a->count > 0.0)) return -22;
+  hipLaunchKernelGGL(sa_reduce_finalize_kernel, dim3(sa_div_up(a->n, 32), a->nbatch), dim3(32 * SA_SP_LANES), 0,
+                     reinterpret_cast<hipStream_t>(stream), *a);
+  hipError_t e = hipGetLastError();
+  return e == hipSuccess ? 0 : -(int)e;
+}

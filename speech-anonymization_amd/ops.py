@@ -348,6 +348,44 @@ def sum_partials(part, nbatch, n=None, rows=False):
     return out
 
 
+_tickets = {}
+
+
+def reduce_finalize(mode, part, nbatch, Cc, ncomp=2, count=1.0, gamma=None, beta=None, mean=None, rstd=None,
+                    sign=1.0, dgamma=None, dbeta=None, db=None, run_mean=None, run_var=None, eps=1e-5,
+                    momentum=0.1):
+    """sa_reduce_finalize: the slab sums of `part` ([nbatch][nslab][Cc*ncomp], any trailing layout)
+    and the finaliser that consumes them in ONE launch (SaFinArgs in include/sa_hip.h).  Returns
+    (mean, rstd, scale, shift) for the FWD modes, (c1, c2, c3) for the BWD modes, db for FIN_BIAS.
+    Single-process statistics only (under SyncBatchNorm the sums are all-reduced between the two
+    halves: sum_partials + fin_* stay separate there)."""
+    n = Cc * ncomp
+    dev = part.device
+    nslab = part.numel() // (nbatch * n)
+    a = L.SaFinArgs()
+    a.part, a.nbatch, a.nslab, a.n, a.C, a.ncomp, a.mode = _f(part), nbatch, nslab, n, Cc, ncomp, mode
+    a.count, a.eps, a.momentum, a.sign = float(count), eps, momentum, sign
+    a.gamma, a.beta, a.mean, a.rstd = _f(gamma), _f(beta), _f(mean), _f(rstd)
+    a.dgamma, a.dbeta, a.db, a.run_mean, a.run_var = _f(dgamma), _f(dbeta), _f(db), _f(run_mean), _f(run_var)
+    out = None
+    if mode != L.FIN_IN_FWD:
+        rows = torch.empty(nbatch, n, dtype=torch.float64, device=dev)
+        tk = _tickets.get(dev)
+        if tk is None:                       # zero-initialised once; the kernel resets what it used
+            tk = _tickets[dev] = torch.zeros(256, dtype=torch.int32, device=dev)
+        a.rows, a.tickets = _f(rows), _f(tk)
+    if mode in (L.FIN_IN_FWD, L.FIN_BN_FWD):
+        out = torch.empty(4, nbatch * Cc if mode == L.FIN_IN_FWD else Cc, dtype=torch.float32, device=dev)
+        a.o0, a.o1, a.o2, a.o3 = _f(out[0]), _f(out[1]), _f(out[2]), _f(out[3])
+    elif mode in (L.FIN_IN_BWD, L.FIN_BN_BWD):
+        out = torch.empty(3, nbatch * Cc if mode == L.FIN_IN_BWD else Cc, dtype=torch.float32, device=dev)
+        a.o0, a.o1, a.o2 = _f(out[0]), _f(out[1]), _f(out[2])
+    L.check(L.load().sa_reduce_finalize(C.byref(a), L.stream()), "sa_reduce_finalize")
+    if out is None:
+        return db
+    return tuple(out[i] for i in range(out.shape[0]))
+
+
 def fin_in_fwd(sums, B, Cc, n, gamma, beta, eps=1e-5):
     lib = L.load()
     o = torch.empty(4, B, Cc, dtype=torch.float32, device=sums.device)

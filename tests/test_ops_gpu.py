@@ -714,3 +714,65 @@ def test_model_fp8_precision_report():
         print(prec, {k: f"{v:.3e}" for k, v in rows[prec].items()})
     assert rows["fp8"]["recon"] < 5e-2 and rows["fp8"]["dec_cos"] > 0.9
     assert rows["bf16"]["recon"] < 1e-3
+
+
+@pytest.mark.parametrize("B,nslab,Cc", [(3, 7, 64), (32, 315, 128), (5, 700, 32)])
+def test_reduce_finalize_equals_the_separate_launches(B, nslab, Cc):
+    """sa_reduce_finalize (slab sums + finaliser in one launch, last-arriving workgroup for the sums
+    over utterances) against sa_sum_partials -> sa_fin_*: same fp64 sums in the same order, so the
+    results are BIT-identical -- every mode, twice (the self-resetting tickets)."""
+    from speech_anonymization_amd import _lib as L, ops
+    d = dev()
+    g = torch.Generator().manual_seed(B * 1000 + nslab)
+    part = torch.randn(B, nslab, Cc, 2, generator=g).to(d)
+    part[..., 1] = part[..., 1].abs() * 3 + 1.0            # a plausible sum of squares
+    gamma = (1 + 0.1 * torch.randn(Cc, generator=g)).to(d)
+    beta = (0.1 * torch.randn(Cc, generator=g)).to(d)
+    n_in, n_bn = 4096.0, 4096.0 * B
+
+    def same(a, b):
+        return torch.allclose(a, b, rtol=3e-7, atol=1e-12)
+    for rep in range(2):
+        # InstanceNorm forward
+        rows = ops.sum_partials(part, B)
+        ref = ops.fin_in_fwd(rows, B, Cc, int(n_in), gamma, beta)
+        got = ops.reduce_finalize(L.FIN_IN_FWD, part, B, Cc, count=n_in, gamma=gamma, beta=beta)
+        for a, b in zip(got, ref):
+            assert same(a.reshape(-1), b.reshape(-1))
+        mean, rstd = ref[0].contiguous(), ref[1].contiguous()
+        # InstanceNorm backward (+ d gamma / d beta over utterances)
+        dg0, db0, dg1, db1 = (torch.empty(Cc, device=d) for _ in range(4))
+        ref = ops.fin_norm_bwd(rows, rows, B * Cc, Cc, n_in, gamma, mean, rstd, dgamma=dg0, dbeta=db0)
+        got = ops.reduce_finalize(L.FIN_IN_BWD, part, B, Cc, count=n_in, gamma=gamma, mean=mean, rstd=rstd,
+                                  dgamma=dg1, dbeta=db1)
+        for a, b in zip(got, ref):
+            assert same(a.reshape(-1), b.reshape(-1))
+        assert torch.equal(dg0, dg1) and torch.equal(db0, db1)
+        # BatchNorm forward (per-utterance rows, then over utterances) incl. running statistics
+        rm0, rv0 = torch.zeros(Cc, device=d), torch.ones(Cc, device=d)
+        rm1, rv1 = torch.zeros(Cc, device=d), torch.ones(Cc, device=d)
+        ref = ops.fin_bn_fwd(rows, Cc, n_bn, gamma, beta, rm0, rv0)
+        got = ops.reduce_finalize(L.FIN_BN_FWD, part, B, Cc, count=n_bn, gamma=gamma, beta=beta,
+                                  run_mean=rm1, run_var=rv1)
+        for a, b in zip(got, ref):
+            assert same(a, b)
+        assert same(rm0, rm1) and same(rv0, rv1)
+        bm, br = ref[0].contiguous(), ref[1].contiguous()
+        # BatchNorm backward with the GradReverse sign
+        ref = ops.fin_norm_bwd(rows, rows, Cc, Cc, n_bn, gamma, bm, br, sign=-1.0, dgamma=dg0, dbeta=db0)
+        got = ops.reduce_finalize(L.FIN_BN_BWD, part, B, Cc, count=n_bn, gamma=gamma, mean=bm, rstd=br,
+                                  sign=-1.0, dgamma=dg1, dbeta=db1)
+        for a, b in zip(got, ref):
+            assert same(a, b)
+        assert torch.equal(dg0, dg1) and torch.equal(db0, db1)
+        # bias gradients: two-component slabs and single-component column sums
+        b0, b1 = torch.empty(Cc, device=d), torch.empty(Cc, device=d)
+        ops.fin_bias(rows, B, Cc, b0)
+        ops.reduce_finalize(L.FIN_BIAS, part, B, Cc, db=b1)
+        assert torch.equal(b0, b1)
+        cs = part[..., 0].contiguous()
+        ops.fin_bias(ops.sum_partials(cs.view(B, nslab, Cc, 1), B), B, Cc, b0, ncomp=1)
+        ops.reduce_finalize(L.FIN_BIAS, cs, B, Cc, ncomp=1, db=b1)
+        assert torch.equal(b0, b1)
+    torch.cuda.synchronize()
+    assert int(ops._tickets[torch.device(d)].abs().sum()) == 0        # every ticket went back to zero
