@@ -67,7 +67,7 @@ struct PPCfg : ConvCfg<T, CIN, COUT, SA, U, TM> {
 // memory half.  NG = 2 with 64-row tiles puts TWO waves per SIMD on the matrix pipe (they cover
 // each other's LDS / weight-fragment latencies) at the 128-register budget of 4 waves per SIMD.
 template <typename T, int CIN, int COUT, int SA, int U, int TM, bool PRO2, int NG>
-__global__ __launch_bounds__(512 * NG, 2 * NG) void sa_conv_pp_kernel(SaConvArgs a, int tiles_per_wg,
+__global__ __launch_bounds__(512 * NG, TM == 64 ? 4 : 2 * NG) void sa_conv_pp_kernel(SaConvArgs a, int tiles_per_wg,
                                                                      int total_tiles, int buf_bytes,
                                                                      int col_off) {
   typedef PPCfg<T, CIN, COUT, SA, U, TM> C;
@@ -118,7 +118,7 @@ __global__ __launch_bounds__(512 * NG, 2 * NG) void sa_conv_pp_kernel(SaConvArgs
     constexpr int NIT = ((C::BMB - 1) * SA + 1 + SA_MAX_HALO + C::RPPI - 1) / C::RPPI;
     // the rows go through registers in PASSES portions (all loads of a portion in flight at once;
     // the other group's MFMA phase covers the latency)
-    constexpr int PASSES = (PRO2 && NIT > 12) ? 2 : 1;
+    constexpr int PASSES = (PRO2 && NIT > 6) ? 2 : 1;
     constexpr int NPP = (NIT + PASSES - 1) / PASSES;
     float k1[VEC], k2[VEC], k3[VEC], csum[VEC], ps[VEC], pq[VEC];
 #pragma unroll
@@ -384,32 +384,38 @@ __global__ __launch_bounds__(512 * NG, 2 * NG) void sa_conv_pp_kernel(SaConvArgs
         if constexpr (EPM) {
           // the stored forward tensor (and the optional second gradient) at this lane's positions:
           // all 16 (32) loads of the m-tile are in flight before the first is used
-          float x[16], g2[16];
 #pragma unroll
-          for (int i = 0; i < 16; ++i) {
+          for (int h8 = 0; h8 < 2; ++h8) {
+          float x[8], g2[8];
+#pragma unroll
+          for (int ii = 0; ii < 8; ++ii) {
+            const int i = h8 * 8 + ii;
             const int o = (mb + (i & 3) + 8 * (i >> 2)) * U + ph;
             const bool ok = FULL || o < a.Lout;
-            x[i] = ok ? xe[(size_t)o * COUT] : 0.0f;
-            g2[i] = (ge && ok) ? ge[(size_t)o * COUT] : 0.0f;
+            x[ii] = ok ? xe[(size_t)o * COUT] : 0.0f;
+            g2[ii] = (ge && ok) ? ge[(size_t)o * COUT] : 0.0f;
           }
 #pragma unroll
-          for (int i = 0; i < 16; ++i) {
+          for (int ii = 0; ii < 8; ++ii) {
+            const int i = h8 * 8 + ii;
             const int o = (mb + (i & 3) + 8 * (i >> 2)) * U + ph;
             // mode 1: g' = (g + g2) * swish'(z), xhat from x (InstanceNorm + x*sigmoid(x) block)
             // mode 2: g' = g + g2, xhat from x, or from swish(z) when ep_xp_is_act (BatchNorm blocks)
-            const float z = fmaf(x[i], es1, et1);
-            float gg2 = g2[i];
+            const float z = fmaf(x[ii], es1, et1);
+            float gg2 = g2[ii];
             if (g2k) gg2 = fmaf(gk1, gg2, fmaf(gk2, sa_swish(z), gk3));
             float gg = acc[mt][i] + bv;
             if (a.relu) gg = fmaxf(gg, 0.0f);
             gg += gg2;
             if (a.ep_mode == 1) gg *= sa_swish_grad(z);
-            const float xv = a.ep_xp_is_act ? sa_swish(z) : x[i];
+            const float xv = a.ep_xp_is_act ? sa_swish(z) : x[ii];
             const float xn = (xv - emu) * ers;
             if (FULL || o < a.Lout) {
               yb[(size_t)o * COUT] = gg;
               ssum += gg; ssq = fmaf(gg, xn, ssq);
             }
+          }
+          __builtin_amdgcn_sched_barrier(0);
           }
         } else {
 #pragma unroll
@@ -551,8 +557,9 @@ static int launch_pp_tm(const SaConvArgs& a, hipStream_t st) {
   if constexpr (CI == 64 && CO == 32 && UU == 2) {
     return launch_pp<T, CI, CO, S, UU, 128, PRO2, 1>(a, st);
   } else {
-    // 64-row tiles run with two sub-groups per phase (1024 threads), 128-row tiles with one
-    return sa_pp_tile_rows(CI, CO, UU) == 64 ? launch_pp<T, CI, CO, S, UU, 64, PRO2, 2>(a, st)
+    // 64-row tiles: two 512-thread workgroups per CU (128-register budget), i.e. two waves per
+    // SIMD in the MFMA half and two in the memory half; 128-row tiles: one workgroup per CU
+    return sa_pp_tile_rows(CI, CO, UU) == 64 ? launch_pp<T, CI, CO, S, UU, 64, PRO2, 1>(a, st)
                                              : launch_pp<T, CI, CO, S, UU, 128, PRO2, 1>(a, st);
   }
 }
