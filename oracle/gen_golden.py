@@ -203,6 +203,32 @@ def loss_fixtures():
         idx_sets.append(np.array(idx))
     o_list, o_mean, o_std = L.group_sampling_mi(X, y, [torch.from_numpy(i) for i in idx_sets])
     assert np.allclose([float(v) for v in mi_list], [float(v) for v in o_list], atol=1e-6)
+    # second case at the batch size the bench uses (N = 32, D = 40, many exact distance ties: rows
+    # are duplicated so that d <= anchor counts are decided by equality, which is index work)
+    X32 = torch.from_numpy(rs.standard_normal((32, 40)).astype("float32"))
+    y32 = torch.from_numpy(rs.randint(0, 2, 32)).long()
+    X32[y32 == 1] += 0.5
+    X32[5], X32[17], X32[20] = X32[3].clone(), X32[3].clone(), X32[11].clone()
+    y32[5], y32[17], y32[20] = y32[3], y32[3], y32[11]
+    mi32_ref = ClusterMI(n_classes=2, k=3)(X32, y32)
+    assert abs(float(mi32_ref) - float(L.cluster_mi(X32, y32))) < 1e-6
+    groups32 = y32.numpy().tolist()
+    np.random.seed(321)
+    with contextlib.redirect_stdout(io.StringIO()), contextlib.redirect_stderr(io.StringIO()):
+        mi32_list, _, _ = GroupSamplingMI(n_samples=8, n_classes=2, n_iterations=8)(X32, y32, groups32)
+    np.random.seed(321)
+    gs32 = {g: np.array([i for i, v in enumerate(groups32) if v == g]) for g in sorted(set(groups32))}
+    idx32 = []
+    for _ in range(8):
+        idx = []
+        for g in gs32:
+            idx.extend(gs32[g][np.random.choice(len(gs32[g]), 8, replace=False)])
+        idx32.append(np.array(idx))
+    o32, _, _ = L.group_sampling_mi(X32, y32, [torch.from_numpy(i) for i in idx32])
+    assert np.allclose([float(v) for v in mi32_list], [float(v) for v in o32], atol=1e-6)
+    np.savez_compressed(os.path.join(OUT, "losses_n32.npz"), X=X32.numpy(), y=y32.numpy(),
+                        mi=np.array(float(mi32_ref)), idx_sets=np.stack(idx32),
+                        mi_list=np.array([float(v) for v in mi32_list]))
     np.savez_compressed(os.path.join(OUT, "losses.npz"), x1=x1.numpy(), x2=x2.numpy(),
                         cos_loss=cos_ref.numpy(), X=X.numpy(), y=y.numpy(),
                         mi=np.array(float(mi_ref)), idx_sets=np.stack(idx_sets),

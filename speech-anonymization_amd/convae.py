@@ -118,6 +118,13 @@ class ConvAutoencoder(nn.Module):
         # within the run-to-run spread), so the separate sa_sum_partials / sa_fin_* launches stay
         # the default (they are also what runs wherever the sums are all-reduced first).
         self.fused_finalize = os.environ.get("SA_FUSED_FINALIZE", "0") == "1"
+        # The FC head of the classifier is ~12 (forward) / ~25 (backward) launches of 5-10 us each
+        # that nothing else waits for until the branches merge: True runs them on a side stream
+        # beside the decoder's convolutions (forward: after the pooling; backward: the decoder's
+        # backward is issued first).  Measured neutral (B = 32: 9.75-9.78 vs 9.77-9.88 ms; B = 10:
+        # 4.02-4.08 vs 4.02 ms), so off by default; never under SyncBatchNorm (the head then
+        # contains collectives).
+        self.overlap_head = os.environ.get("SA_OVERLAP_HEAD", "0") == "1"
 
     def forward(self, feats):
         # walking the module tree costs ~0.15 ms a call: the (names, parameters) lists are cached
@@ -139,6 +146,11 @@ class ConvAutoencoder(nn.Module):
         if getattr(self, "_wgs", None) is None and device.type == "cuda":
             self._wgs = torch.cuda.Stream(device=device)
         return getattr(self, "_wgs", None)
+
+    def _head_stream(self, device):
+        if getattr(self, "_hs", None) is None and device.type == "cuda":
+            self._hs = torch.cuda.Stream(device=device)
+        return getattr(self, "_hs", None)
 
     def _side_stream(self, device):
         if getattr(self, "_side", None) is None and device.type == "cuda":
@@ -366,15 +378,25 @@ class _ConvAEFn(torch.autograd.Function):
                                s2=bn1[2], t2=bn1[3], relu=True, want_stats=True)
         bn2 = bn_stats(st, B * Lc, cls.tdnn[8], "sex_classifier.tdnn.8", 128, 3)
         pooled, pmean, psd = ops.pool_fwd(r2, bn2[2], bn2[3], noise=_noise(model, B, feats.device))
-        H1 = ops.dense(pooled, P["sex_classifier.classify.0.weight"], P["sex_classifier.classify.0.bias"],
-                       128, 256, relu=True)
-        f1 = bnorm(ops.colsums(H1) if train else None, B, cls.classify[2], "sex_classifier.classify.2", 128, 4)
-        H2 = ops.dense(H1, P["sex_classifier.classify.3.weight"], P["sex_classifier.classify.3.bias"],
-                       64, 128, ps=f1[2], pt=f1[3], relu=True)
-        f2 = bnorm(ops.colsums(H2) if train else None, B, cls.classify[5], "sex_classifier.classify.5", 64, 5)
-        logits = ops.dense(H2, P["sex_classifier.classify.6.weight"], P["sex_classifier.classify.6.bias"],
-                           2, 64, ps=f2[2], pt=f2[3])
-        logp = ops.log_softmax(logits)
+        def head_fwd():
+            H1 = ops.dense(pooled, P["sex_classifier.classify.0.weight"], P["sex_classifier.classify.0.bias"],
+                           128, 256, relu=True)
+            f1 = bnorm(ops.colsums(H1) if train else None, B, cls.classify[2], "sex_classifier.classify.2", 128, 4)
+            H2 = ops.dense(H1, P["sex_classifier.classify.3.weight"], P["sex_classifier.classify.3.bias"],
+                           64, 128, ps=f1[2], pt=f1[3], relu=True)
+            f2 = bnorm(ops.colsums(H2) if train else None, B, cls.classify[5], "sex_classifier.classify.5", 64, 5)
+            logits = ops.dense(H2, P["sex_classifier.classify.6.weight"], P["sex_classifier.classify.6.bias"],
+                               2, 64, ps=f2[2], pt=f2[3])
+            return H1, f1, H2, f2, ops.log_softmax(logits)
+
+        hs = model._head_stream(feats.device) if (model.overlap_head and not model._bn_syncs()) else None
+        if hs is None:
+            H1, f1, H2, f2, logp = head_fwd()
+        else:                                  # beside the decoder's convolutions
+            main = torch.cuda.current_stream()
+            hs.wait_stream(main)
+            with torch.cuda.stream(hs):
+                H1, f1, H2, f2, logp = head_fwd()
         # ---------------- decoder ----------------
         y6, st = cg(y5, pw("decoder.1.weight", "convT_fwd"), "decoder.1.weight", P["decoder.1.bias"], 128, 64, 1, 2,
                                ops.UP2, L2, want_stats=True)
@@ -385,6 +407,10 @@ class _ConvAEFn(torch.autograd.Function):
                                ops.UP2, Ltot, want_stats=True)
         n8 = inorm(st, Ltot, "decoder.6", 32)
         recon = ops.convCto1(y8, P["decoder.8.weight"], P["decoder.8.bias"], n8[2], n8[3], True)
+        if hs is not None:
+            main.wait_stream(hs)
+            for tns in (H1, H2, logp, f1[0], f2[0]):      # allocated on the side stream, consumed on this one
+                tns.record_stream(main)
 
         if tracked:
             torch._foreach_add_(tracked, 1)
@@ -587,47 +613,7 @@ class _ConvAEFn(torch.autograd.Function):
         if d_logp is None:
             d_logp = torch.zeros(B, 2, device=dev)
 
-        # ======================= sex classifier (first: its input gradient is an addend of the
-        # encoder-output gradient that the last decoder dgrad fuses in) =======================
-        c = "sex_classifier.classify."
-        dLG = ops.log_softmax_bwd(d_logp.contiguous().float(), S["logp"])
-        H1, H2 = S["H1"], S["H2"]
-        G[c + "6.weight"] = ops.dense_wgrad(dLG, H2, newg(c + "6.weight"), ps=f2[2], pt=f2[3])
-        setg(c + "6.bias", ops.colsums(dLG)[:, 0])
-        dN2 = ops.dense(dLG, P[c + "6.weight"], None, 64, 2, transpose_w=True)
-        l2 = ops.colsums(dN2, H2, f2[0], f2[1]); g2s, _ = model._bn_global(l2)
-        setg(c + "5.weight", l2[:, 1]); setg(c + "5.bias", l2[:, 0])
-        dH2 = ops.bn2d_bwd(dN2, H2, g2s, B, P[c + "5.weight"], f2[0], f2[1], True, count_dev=cdev(5))
-        G[c + "3.weight"] = ops.dense_wgrad(dH2, H1, newg(c + "3.weight"), ps=f1[2], pt=f1[3])
-        setg(c + "3.bias", ops.colsums(dH2)[:, 0])
-        dN1 = ops.dense(dH2, P[c + "3.weight"], None, 128, 64, transpose_w=True)
-        l1 = ops.colsums(dN1, H1, f1[0], f1[1]); g1s, _ = model._bn_global(l1)
-        setg(c + "2.weight", l1[:, 1]); setg(c + "2.bias", l1[:, 0])
-        dH1 = ops.bn2d_bwd(dN1, H1, g1s, B, P[c + "2.weight"], f1[0], f1[1], True, count_dev=cdev(4))
-        G[c + "0.weight"] = ops.dense_wgrad(dH1, S["pooled"], newg(c + "0.weight"))
-        setg(c + "0.bias", ops.colsums(dH1)[:, 0])
-        dP = ops.dense(dH1, P[c + "0.weight"], None, 256, 128, transpose_w=True)
-        t = "sex_classifier.tdnn."
-        g, st = ops.pool_bwd(r2, bn2[2], bn2[3], dP, S["pmean"], S["psd"], bn=(bn2[0], bn2[1]))
-        g = bn_finish(g, st, r2, bn2, Lc, t + "8", t + "6.bias", 3)
-        conv_wgrad(t + "6.weight", r1, g, 128, 128, 1, Lc, 3, 3, 0, s2=bn1[2], t2=bn1[3])
-        g, st = cg(g, pw(t + "6.weight", "conv_dgrad"), None, 128, 128, 1, 1,
-                   ops.taps_conv_dgrad_s1(3, 3, 0), Lb, want_stats=True, ep=bn_ep(r1, bn1))
-        g = bn_finish(g, st, r1, bn1, Lb, t + "5", t + "3.bias", 2)
-        conv_wgrad(t + "3.weight", r0, g, 128, 128, 1, Lb, 3, 2, 0, s2=bn0[2], t2=bn0[3])
-        g, st = cg(g, pw(t + "3.weight", "conv_dgrad"), None, 128, 128, 1, 1,
-                   ops.taps_conv_dgrad_s1(3, 2, 0), La, want_stats=True, ep=bn_ep(r0, bn0))
-        g = bn_finish(g, st, r0, bn0, La, t + "2", t + "0.bias", 1)
-        conv_wgrad(t + "0.weight", y4, g, 128, 128, 1, La, 5, 1, 0, s1=n4[2], t1=n4[3], swish=True,
-                   s2=bn_n[2], t2=bn_n[3])
-        xp4 = (n4[2], n4[3])
-        g, st = cg(g, pw(t + "0.weight", "conv_dgrad"), None, 128, 128, 1, 1,
-                   ops.taps_conv_dgrad_s1(5, 1, 0), L4, want_stats=True, ep=bn_ep(y4, bn_n, xp4))
-        da4_cls = bn_finish(g, st, y4, bn_n, L4, "sex_classifier.norm", None, 0, xp=xp4)      # includes GRL
-        side_join()
-        if need_stage["sex_classifier"]:
-            buckets.reduce_stage("sex_classifier")
-        if not run_decoder:                       # classifier-only step: nothing below needs a gradient
+        def finish():
             buckets.join()
             ctx.S = None
             grads = tuple(G[k] if need[k] else None for k in names)
@@ -635,41 +621,101 @@ class _ConvAEFn(torch.autograd.Function):
             buckets.views.clear()
             return (None, None, None) + grads
 
+        # ======================= sex classifier: FC head =======================
+        def head_bwd():
+            c = "sex_classifier.classify."
+            dLG = ops.log_softmax_bwd(d_logp.contiguous().float(), S["logp"])
+            H1, H2 = S["H1"], S["H2"]
+            G[c + "6.weight"] = ops.dense_wgrad(dLG, H2, newg(c + "6.weight"), ps=f2[2], pt=f2[3])
+            setg(c + "6.bias", ops.colsums(dLG)[:, 0])
+            dN2 = ops.dense(dLG, P[c + "6.weight"], None, 64, 2, transpose_w=True)
+            l2 = ops.colsums(dN2, H2, f2[0], f2[1]); g2s, _ = model._bn_global(l2)
+            setg(c + "5.weight", l2[:, 1]); setg(c + "5.bias", l2[:, 0])
+            dH2 = ops.bn2d_bwd(dN2, H2, g2s, B, P[c + "5.weight"], f2[0], f2[1], True, count_dev=cdev(5))
+            G[c + "3.weight"] = ops.dense_wgrad(dH2, H1, newg(c + "3.weight"), ps=f1[2], pt=f1[3])
+            setg(c + "3.bias", ops.colsums(dH2)[:, 0])
+            dN1 = ops.dense(dH2, P[c + "3.weight"], None, 128, 64, transpose_w=True)
+            l1 = ops.colsums(dN1, H1, f1[0], f1[1]); g1s, _ = model._bn_global(l1)
+            setg(c + "2.weight", l1[:, 1]); setg(c + "2.bias", l1[:, 0])
+            dH1 = ops.bn2d_bwd(dN1, H1, g1s, B, P[c + "2.weight"], f1[0], f1[1], True, count_dev=cdev(4))
+            G[c + "0.weight"] = ops.dense_wgrad(dH1, S["pooled"], newg(c + "0.weight"))
+            setg(c + "0.bias", ops.colsums(dH1)[:, 0])
+            return ops.dense(dH1, P[c + "0.weight"], None, 256, 128, transpose_w=True)
+
+        # ======================= sex classifier: pooling + TDNN (its input gradient is an addend
+        # of the encoder-output gradient that the last decoder dgrad fuses in) =======================
+        def tdnn_bwd(dP):
+            t = "sex_classifier.tdnn."
+            g, st = ops.pool_bwd(r2, bn2[2], bn2[3], dP, S["pmean"], S["psd"], bn=(bn2[0], bn2[1]))
+            g = bn_finish(g, st, r2, bn2, Lc, t + "8", t + "6.bias", 3)
+            conv_wgrad(t + "6.weight", r1, g, 128, 128, 1, Lc, 3, 3, 0, s2=bn1[2], t2=bn1[3])
+            g, st = cg(g, pw(t + "6.weight", "conv_dgrad"), None, 128, 128, 1, 1,
+                       ops.taps_conv_dgrad_s1(3, 3, 0), Lb, want_stats=True, ep=bn_ep(r1, bn1))
+            g = bn_finish(g, st, r1, bn1, Lb, t + "5", t + "3.bias", 2)
+            conv_wgrad(t + "3.weight", r0, g, 128, 128, 1, Lb, 3, 2, 0, s2=bn0[2], t2=bn0[3])
+            g, st = cg(g, pw(t + "3.weight", "conv_dgrad"), None, 128, 128, 1, 1,
+                       ops.taps_conv_dgrad_s1(3, 2, 0), La, want_stats=True, ep=bn_ep(r0, bn0))
+            g = bn_finish(g, st, r0, bn0, La, t + "2", t + "0.bias", 1)
+            conv_wgrad(t + "0.weight", y4, g, 128, 128, 1, La, 5, 1, 0, s1=n4[2], t1=n4[3], swish=True,
+                       s2=bn_n[2], t2=bn_n[3])
+            xp4 = (n4[2], n4[3])
+            g, st = cg(g, pw(t + "0.weight", "conv_dgrad"), None, 128, 128, 1, 1,
+                       ops.taps_conv_dgrad_s1(5, 1, 0), L4, want_stats=True, ep=bn_ep(y4, bn_n, xp4))
+            da = bn_finish(g, st, y4, bn_n, L4, "sex_classifier.norm", None, 0, xp=xp4)      # includes GRL
+            side_join()
+            if need_stage["sex_classifier"]:
+                buckets.reduce_stage("sex_classifier")
+            return da
+
         # ======================= decoder =======================
-        if recon_unused:
-            d_recon = torch.zeros(B, T, 80, device=dev)
-        g_rec = d_recon.reshape(B, Ltot).contiguous().float()
-        if need["decoder.8.bias"]:
-            setg("decoder.8.bias", ops.sum_partials(g_rec.view(4 * B, Ltot // 4), 1, n=Ltot // 4).sum())
-        if need["decoder.8.weight"]:
-            G["decoder.8.weight"] = ops.wgrad1C(g_rec, y8, newg("decoder.8.weight"), flip=True,
-                                                s1=n8[2], t1=n8[3], swish=True)
-        g, st = ops.conv1toC(g_rec, P["decoder.8.weight"], None, dt, flip=True, want_stats=True,
-                             ep=dict(x=y8, s1=n8[2], t1=n8[3], mean=n8[0], rstd=n8[1]))     # d z8
-        g = in_finish(g, st, y8, n8, 32, Ltot, "decoder.6", "decoder.5.bias")               # d y8
-        convT_wgrad("decoder.5.weight", y7, g, 64, 32, L2)
-        g, st = cg(g, pw("decoder.5.weight", "convT_dgrad"), None, 32, 64, 2, 1,
-                   ops.taps_convT_dgrad(), L2, want_stats=True)                              # d y7
-        bias_from(st, "decoder.4.bias", 64)
-        conv_wgrad("decoder.4.weight", y6, g, 64, 64, 1, L2, K5, 1, 2, s1=n6[2], t1=n6[3], swish=True)
-        g, st = cg(g, pw("decoder.4.weight", "conv_dgrad"), None, 64, 64, 1, 1,
-                   ops.taps_conv_dgrad_s1(K5, 1, 2), L2, want_stats=True, ep=in_ep(y6, n6))  # d z6
-        g = in_finish(g, st, y6, n6, 64, L2, "decoder.2", "decoder.1.bias")                 # d y6
-        convT_wgrad("decoder.1.weight", y5, g, 128, 64, L4)
-        g, st = cg(g, pw("decoder.1.weight", "convT_dgrad"), None, 64, 128, 2, 1,
-                   ops.taps_convT_dgrad(), L4, want_stats=True)                              # d y5
-        bias_from(st, "decoder.0.bias", 128)
-        conv_wgrad("decoder.0.weight", y4, g, 128, 128, 1, L4, K5, 1, 2, s1=n4[2], t1=n4[3], swish=True)
-        side_join()
-        if need_stage["decoder"]:
-            buckets.reduce_stage("decoder")
+        def decoder_bwd():
+            d_rec = torch.zeros(B, T, 80, device=dev) if recon_unused else d_recon
+            g_rec = d_rec.reshape(B, Ltot).contiguous().float()
+            if need["decoder.8.bias"]:
+                setg("decoder.8.bias", ops.sum_partials(g_rec.view(4 * B, Ltot // 4), 1, n=Ltot // 4).sum())
+            if need["decoder.8.weight"]:
+                G["decoder.8.weight"] = ops.wgrad1C(g_rec, y8, newg("decoder.8.weight"), flip=True,
+                                                    s1=n8[2], t1=n8[3], swish=True)
+            g, st = ops.conv1toC(g_rec, P["decoder.8.weight"], None, dt, flip=True, want_stats=True,
+                                 ep=dict(x=y8, s1=n8[2], t1=n8[3], mean=n8[0], rstd=n8[1]))     # d z8
+            g = in_finish(g, st, y8, n8, 32, Ltot, "decoder.6", "decoder.5.bias")               # d y8
+            convT_wgrad("decoder.5.weight", y7, g, 64, 32, L2)
+            g, st = cg(g, pw("decoder.5.weight", "convT_dgrad"), None, 32, 64, 2, 1,
+                       ops.taps_convT_dgrad(), L2, want_stats=True)                              # d y7
+            bias_from(st, "decoder.4.bias", 64)
+            conv_wgrad("decoder.4.weight", y6, g, 64, 64, 1, L2, K5, 1, 2, s1=n6[2], t1=n6[3], swish=True)
+            g, st = cg(g, pw("decoder.4.weight", "conv_dgrad"), None, 64, 64, 1, 1,
+                       ops.taps_conv_dgrad_s1(K5, 1, 2), L2, want_stats=True, ep=in_ep(y6, n6))  # d z6
+            g = in_finish(g, st, y6, n6, 64, L2, "decoder.2", "decoder.1.bias")                 # d y6
+            convT_wgrad("decoder.1.weight", y5, g, 128, 64, L4)
+            g, st = cg(g, pw("decoder.1.weight", "convT_dgrad"), None, 64, 128, 2, 1,
+                       ops.taps_convT_dgrad(), L4, want_stats=True)                              # d y5
+            bias_from(st, "decoder.0.bias", 128)
+            conv_wgrad("decoder.0.weight", y4, g, 128, 128, 1, L4, K5, 1, 2, s1=n4[2], t1=n4[3], swish=True)
+            side_join()
+            if need_stage["decoder"]:
+                buckets.reduce_stage("decoder")
+            return g
+
+        hs = (model._head_stream(dev) if (model.overlap_head and run_decoder and not model._bn_syncs()
+                                         and dev.type == "cuda") else None)
+        if hs is None:
+            da4_cls = tdnn_bwd(head_bwd())
+            if not run_decoder:                   # classifier-only step: nothing below needs a gradient
+                return finish()
+            g = decoder_bwd()
+        else:
+            # the head's ~25 small launches on the side stream beside the decoder's backward
+            main = torch.cuda.current_stream()
+            hs.wait_stream(main)
+            with torch.cuda.stream(hs):
+                dP = head_bwd()
+            g = decoder_bwd()
+            main.wait_stream(hs)
+            dP.record_stream(main)
+            da4_cls = tdnn_bwd(dP)
         if not run_encoder:
-            buckets.join()
-            ctx.S = None
-            grads = tuple(G[k] if need[k] else None for k in names)
-            G.clear()
-            buckets.views.clear()
-            return (None, None, None) + grads
+            return finish()
 
         # ======================= encoder =======================
         # d z4 = (decoder.0 dgrad + classifier branch) * swish'(z4), fused into the dgrad launch

@@ -473,6 +473,15 @@ def test_cosine_and_mi_golden(golden_dir):
     torch.cuda.synchronize()
     assert abs(float(mi[0]) - float(z["mi"])) < 1e-4
     assert np.allclose(mis.cpu().numpy(), z["mi_list"], atol=1e-4)
+    # second reference-generated case: N = 32 (the bench's batch size) with duplicated rows, i.e.
+    # exact ties in `d <= anchor` (utils/ClusterMI.py:115) -- neighbour counting is index work
+    z = np.load(os.path.join(golden_dir, "losses_n32.npz"))
+    X, y = torch.from_numpy(z["X"]).to(dev()), torch.from_numpy(z["y"]).to(dev())
+    mi = ops.cluster_mi(X, y)
+    mis = ops.cluster_mi(X, y, torch.from_numpy(z["idx_sets"]).long().to(dev()))
+    torch.cuda.synchronize()
+    assert abs(float(mi[0]) - float(z["mi"])) < 1e-4
+    assert np.allclose(mis.cpu().numpy(), z["mi_list"], atol=1e-4)
 
 
 @pytest.mark.parametrize("mode", ["utterance", "batch"])

@@ -47,6 +47,34 @@ def test_losses_match_reference_vectors(golden_dir):
     assert abs(float(mean) - float(z["mi_mean"])) < 1e-6 and abs(float(std) - float(z["mi_std"])) < 1e-6
 
 
+def test_mi_and_endtoend_oracle_match_reference_vectors(golden_dir):
+    """the round-2 fixtures: N = 32 MI case with exact distance ties; ConvReconstruction
+    (models/EndToEnd.py) with the seeded oracle x-vector as its frozen classifier"""
+    z = np.load(os.path.join(golden_dir, "losses_n32.npz"))
+    X, y = torch.from_numpy(z["X"]), torch.from_numpy(z["y"])
+    assert abs(float(L.cluster_mi(X, y)) - float(z["mi"])) < 1e-6
+    lst, _, _ = L.group_sampling_mi(X, y, [torch.from_numpy(i) for i in z["idx_sets"]])
+    assert np.allclose([float(v) for v in lst], z["mi_list"], atol=1e-6)
+    from oracle import endtoend as OE
+    torch.set_num_threads(1)
+    z = np.load(os.path.join(golden_dir, "endtoend_S.npz"))
+    clf = OE.OracleEncoderClassifier()
+    clf.load_state_dict(OE.numpy_params(clf, 1230))
+    clf.eval()
+    m = OE.ConvReconstruction(clf)
+    m.load_state_dict({k: v for k, v in OE.numpy_params(m, 8886).items() if k.startswith("encoder.")}, strict=False)
+    m.train(); clf.eval()
+    recon, logp = m(torch.from_numpy(z["feats"]))
+    w = [float(v) for v in z["weights"]]
+    loss = (w[0] * L.recon_loss(recon, torch.from_numpy(z["target"]), "l1") - w[1] * L.sex_loss(logp, torch.from_numpy(z["gender"]))
+            - w[3] * L.confusion_loss(logp))
+    assert torch.equal(recon.detach(), torch.from_numpy(z["recon"])) and abs(float(loss) - float(z["loss"])) < 1e-6
+    loss.backward()
+    g = m.encoder[3].weight.grad.reshape(-1)
+    step = max(1, g.numel() // 2048)
+    assert np.allclose(g[::step][:2048].numpy(), z["grad_sub/encoder.3.weight"], rtol=1e-5, atol=1e-8)
+
+
 def test_noam_schedule_matches_train_log(golden_dir):
     pins = json.load(open(os.path.join(golden_dir, "reference_pins.json")))
     rows = pins["noam_train_log"]["steps_lr"]
