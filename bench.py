@@ -196,7 +196,8 @@ def cpu_baseline():
 
 def run_config(args, batch_size, rank, world, device, profile_key=None):
     """SETUP_STEPS + args.warmup un-timed steps, then EXACTLY args.steps timed steps between
-    barrier + synchronize on both sides; returns (elapsed max over ranks, last loss, profile)."""
+    barrier + synchronize on both sides; returns (elapsed max over ranks, last loss, profile of the
+    dominant kernel, graph mode, host time spent issuing one step)."""
     import torch
     from speech_anonymization_amd import ops
     graph = world == 1 and args.graph
@@ -224,7 +225,7 @@ def run_config(args, batch_size, rank, world, device, profile_key=None):
     host_issue = time.perf_counter() - t0            # the host has ISSUED all steps (no wait in the loop)
     sync_all()
     elapsed = time.perf_counter() - t0
-    run_config.host_ms_per_step = host_issue / args.steps * 1e3
+    host_ms = host_issue / args.steps * 1e3
     prof = ops.PROFILE.collect() if profile_key and not graph else None
     loss = float(loss)
     if profile_key and graph:
@@ -248,7 +249,7 @@ def run_config(args, batch_size, rank, world, device, profile_key=None):
         tt = torch.tensor([elapsed], device=device, dtype=torch.float64)
         torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
         elapsed = float(tt)
-    return elapsed, loss, prof, graph
+    return elapsed, loss, prof, graph, host_ms
 
 
 def roofline_of(prof, dtype):
@@ -346,18 +347,17 @@ def main(argv=None):
     device = torch.device("cuda", local_rank)
     torch.cuda.set_device(device)
 
-    elapsed, loss, prof, graph = run_config(args, args.batch, rank, world, device,
-                                            profile_key="conv_gemm(128,128,1,1)")
-    host_b = run_config.host_ms_per_step
+    elapsed, loss, prof, graph, host_b = run_config(args, args.batch, rank, world, device,
+                                                    profile_key="conv_gemm(128,128,1,1)")
     frames = world * args.batch * T * args.steps
     value = frames / elapsed
     if rank == 0:
         note(f"B={args.batch}: {value:.4g} frames/s, {elapsed / args.steps * 1e3:.3f} ms/step")
     b10 = None
     if not args.no_b10 and args.batch != 10 and args.samples == N_SAMPLES:
-        e10, l10, _, _ = run_config(args, 10, rank, world, device)
+        e10, l10, _, _, host10 = run_config(args, 10, rank, world, device)
         b10 = {"batch_per_gpu": 10, "value": world * 10 * T * args.steps / e10, "unit": "frames/s",
-               "ms_per_step": e10 / args.steps * 1e3, "host_issue_ms_per_step": run_config.host_ms_per_step,
+               "ms_per_step": e10 / args.steps * 1e3, "host_issue_ms_per_step": host10,
                "loss": l10}
 
     if rank == 0:

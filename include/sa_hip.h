@@ -89,6 +89,9 @@ typedef struct SaConvArgs {
   float* pro_stats;
   /* SA_FP8: device scalar the e4m3 weight image was multiplied with (accumulators are divided by it) */
   const float* wscale;
+  /* output rows per workgroup of THIS launch on the one-tile kernel: 0 = the per-shape policy, 64 or
+   * 128 (size `stats` with sa_conv_gemm_ntiles_tm) */
+  int tile_rows; int pad2_;
 } SaConvArgs;
 
 int sa_conv_gemm(int dtype, int cin, int cout, int sa, int u, const SaConvArgs* a, void* stream);
@@ -96,6 +99,7 @@ int sa_conv_gemm(int dtype, int cin, int cout, int sa, int u, const SaConvArgs* 
  * verify its mirror of these records (the library reads every field) */
 int sa_abi_sizeof(int which);
 int sa_conv_gemm_ntiles(int cin, int cout, int u, int Lout);
+int sa_conv_gemm_ntiles_tm(int tile_rows, int u, int Lout);       /* tiles per utterance at an explicit tile height */
 int sa_conv_gemm_set_tile_rows(int rows);   /* tuning knob: 0 (default policy), 64 or 128 */
 /* Geometry of a launch with this dtype code and shape: *ntiles = slabs per utterance of nb_colsum /
  * pro_stats ([B][*ntiles][cin] / [B][*ntiles][cin][2]), *nslabs = statistics slabs per utterance

@@ -35,7 +35,8 @@ class SaConvArgs(C.Structure):
                 ("a_out", vp),
                 ("nb_x", vp), ("nb_c1", vp), ("nb_c2", vp), ("nb_c3", vp),
                 ("nb_bstride", C.c_int), ("nb_relu_mask", C.c_int), ("nb_colsum", vp),
-                ("ep_g2k1", vp), ("ep_g2k2", vp), ("ep_g2k3", vp), ("pro_stats", vp), ("wscale", vp)]
+                ("ep_g2k1", vp), ("ep_g2k2", vp), ("ep_g2k3", vp), ("pro_stats", vp), ("wscale", vp),
+                ("tile_rows", C.c_int), ("pad2_", C.c_int)]
 
 
 class SaPackDesc(C.Structure):
@@ -76,7 +77,7 @@ FIN_IN_FWD, FIN_IN_BWD, FIN_BN_FWD, FIN_BN_BWD, FIN_BIAS = 1, 2, 3, 4, 5
 
 # every symbol include/sa_hip.h declares (checked by tests/test_abi.py on CPU)
 SYMBOLS = [
-    "sa_conv_gemm", "sa_abi_sizeof", "sa_conv_gemm_ntiles", "sa_conv_gemm_set_tile_rows",
+    "sa_conv_gemm", "sa_abi_sizeof", "sa_conv_gemm_ntiles", "sa_conv_gemm_ntiles_tm", "sa_conv_gemm_set_tile_rows",
     "sa_conv_gemm_geometry", "sa_conv_gemm_set_impl", "sa_conv_pp_set_tile_rows", "sa_pack_weights", "sa_pack_weights_multi", "sa_pack_scales_multi", "sa_wgrad", "sa_wgrad_kw", "sa_wgrad_reduce",
     "sa_conv1toC", "sa_conv1toC_ntiles", "sa_convCto1", "sa_wgrad1C", "sa_wgrad1C_nchunk",
     "sa_sum_slabs", "sa_ew_stats", "sa_ew_apply", "sa_ew_ntiles", "sa_act_stats",

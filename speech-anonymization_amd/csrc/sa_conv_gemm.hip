@@ -553,10 +553,16 @@ extern "C" int sa_conv_gemm_ntiles(int cin, int cout, int u, int Lout) {
 int sa_conv_pp_dispatch(int dtype, int cin, int cout, int sa, int u, const SaConvArgs* a, hipStream_t st);
 int sa_pp_tile_rows(int cin, int cout, int u);
 int sa_pp_share(int cout);
-static int g_use_pp = 0;
-extern "C" int sa_conv_gemm_set_impl(int pp) {
-  if (pp != 0 && pp != 1) return -22;
-  g_use_pp = pp;
+// sa_conv_gemm_set_impl(2): the 128->128 bf16x3 launches the weight-stationary kernel covers
+// (sa_conv_ws.hip: persistent, one wave per SIMD, weights in registers, rows by LDS-DMA) go there;
+// same slab geometry as this file's 64-row tiles, so nothing else changes for the caller.
+bool sa_conv_ws_covers(int dtype, int cin, int cout, int sa, int u, const SaConvArgs* a);
+int sa_conv_ws_dispatch(const SaConvArgs* a, hipStream_t st);
+static int g_use_pp = 0, g_use_ws = 0;
+extern "C" int sa_conv_gemm_set_impl(int impl) {
+  if (impl < 0 || impl > 2) return -22;
+  g_use_pp = impl == 1;
+  g_use_ws = impl == 2;
   return 0;
 }
 static bool uses_pp(int dtype) { return g_use_pp && (dtype == SA_F32 || dtype == SA_BF16X3); }
@@ -577,13 +583,19 @@ extern "C" int sa_conv_gemm_geometry(int dtype, int cin, int cout, int u, int Lo
   return 0;
 }
 
+extern "C" int sa_conv_gemm_ntiles_tm(int tile_rows, int u, int Lout) {
+  if ((tile_rows != 64 && tile_rows != 128) || u < 1 || Lout < 1) return -22;
+  return sa_div_up(sa_div_up(Lout, u), tile_rows / u);
+}
+
 template <typename T, int CI, int CO, int S, int UU, bool PRO2 = false>
 static int launch_tm(const SaConvArgs& a, hipStream_t st) {
   if constexpr (CI == 64 && CO == 32 && UU == 2) {
     return launch_cfg<T, CI, CO, S, UU, 128, PRO2>(a, st);
   } else {
-    return tile_rows(CI, CO, UU) == 64 ? launch_cfg<T, CI, CO, S, UU, 64, PRO2>(a, st)
-                                       : launch_cfg<T, CI, CO, S, UU, 128, PRO2>(a, st);
+    const int tm = (a.tile_rows == 64 || a.tile_rows == 128) ? a.tile_rows : tile_rows(CI, CO, UU);
+    return tm == 64 ? launch_cfg<T, CI, CO, S, UU, 64, PRO2>(a, st)
+                    : launch_cfg<T, CI, CO, S, UU, 128, PRO2>(a, st);
   }
 }
 
@@ -620,6 +632,8 @@ extern "C" int sa_conv_gemm(int dtype, int cin, int cout, int sa, int u, const S
   if (!a || !a->x || !a->wp || !a->y || a->B <= 0 || a->Lin <= 0 || a->Lout <= 0) return -22;
   if (a->ep_mode < 0 || a->ep_mode > 2 || (a->ep_mode && !a->ep_x)) return -22;
   if (uses_pp(dtype)) return sa_conv_pp_dispatch(dtype, cin, cout, sa, u, a, st);
+  if (g_use_ws && tile_rows(cin, cout, u) == 64 && sa_conv_ws_covers(dtype, cin, cout, sa, u, a))
+    return sa_conv_ws_dispatch(a, st);
   SA_CONV_CASE(32, 64, 2, 1)
   SA_CONV_CASE(64, 64, 1, 1)
   SA_CONV_CASE(64, 128, 2, 1)

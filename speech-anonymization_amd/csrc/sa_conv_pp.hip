@@ -89,7 +89,8 @@ __global__ __launch_bounds__(512 * NG, TM == 64 ? 4 : 2 * NG) void sa_conv_pp_ke
   const int ph = wn / C::NT, nt = wn % C::NT;               // this wave's output phase / column block
 
   f32x16 acc[C::MT];
-  int cur_h = 0;
+  int cur_h = 0;                                            // (half-step index for the stamps build)
+  (void)cur_h;
 
   // ================= load + transform + stage the input rows of tile t =================
   auto stage_tile = [&](int t) {

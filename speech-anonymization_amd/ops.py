@@ -160,12 +160,13 @@ def _conv_geometry(code, cin, cout, u, Lout):
     return nt.value, ns.value
 
 
-def conv_impl(pingpong=False, tile_rows=0, pp_rows=0):
+def conv_impl(pingpong=False, tile_rows=0, pp_rows=0, ws=False):
     """kernel choice for the f32 / bf16x3 policies (A/B timing, kernel tests): the
-    one-tile-per-workgroup kernel (default) or the two-groups-in-anti-phase kernel
-    (sa_conv_pp.hip); tile-row knobs of both (0 = policy)."""
+    one-tile-per-workgroup kernel, the two-groups-in-anti-phase kernel (sa_conv_pp.hip) or the
+    weight-stationary kernel for the 128->128 layers (sa_conv_ws.hip; the other shapes stay on the
+    one-tile kernel); tile-row knobs of the first two (0 = policy)."""
     lib = L.load()
-    L.check(lib.sa_conv_gemm_set_impl(int(bool(pingpong))), "sa_conv_gemm_set_impl")
+    L.check(lib.sa_conv_gemm_set_impl(2 if ws else int(bool(pingpong))), "sa_conv_gemm_set_impl")
     L.check(lib.sa_conv_gemm_set_tile_rows(int(tile_rows)), "sa_conv_gemm_set_tile_rows")
     L.check(lib.sa_conv_pp_set_tile_rows(int(pp_rows)), "sa_conv_pp_set_tile_rows")
     _conv_geometry.cache_clear()

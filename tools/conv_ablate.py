@@ -19,9 +19,10 @@ def one():
     import torch
     from speech_anonymization_amd import _lib as L, ops
     dev = torch.device("cuda:0")
-    if os.environ.get("SA_CONV_IMPL"):          # "old" | "pp128" | "pp64"
+    if os.environ.get("SA_CONV_IMPL"):          # "old" | "old128" | "pp128" | "pp64" | "ws"
         impl = os.environ["SA_CONV_IMPL"]
-        ops.conv_impl(pingpong=impl != "old", pp_rows=64 if impl == "pp64" else 0)
+        ops.conv_impl(pingpong=impl.startswith("pp"), pp_rows=64 if impl == "pp64" else 0,
+                      tile_rows=128 if impl == "old128" else 0, ws=impl == "ws")
     B, L4 = int(os.environ.get("KB_B", "32")), 20160
     code = L.BF16X3
     g = torch.Generator(device="cpu").manual_seed(1)
