@@ -103,12 +103,16 @@ int sa_conv_gemm_ntiles_tm(int tile_rows, int u, int Lout);       /* tiles per u
 int sa_conv_gemm_set_tile_rows(int rows);   /* tuning knob: 0 (default policy), 64 or 128 */
 /* Geometry of a launch with this dtype code and shape: *ntiles = slabs per utterance of nb_colsum /
  * pro_stats ([B][*ntiles][cin] / [B][*ntiles][cin][2]), *nslabs = statistics slabs per utterance
- * (`stats` is [B][*nslabs][cout][2]); the reducers sum slabs in index order.  The f32 and bf16x3 policies run
- * on the two-groups-in-anti-phase kernel (sa_conv_pp.hip), whose waves write one slab per wave that
- * shares a column block; sa_conv_gemm_set_impl(0) routes them to the one-tile-per-workgroup kernel
- * (A/B timing).  sa_conv_pp_set_tile_rows: 0 (policy), 64 or 128. */
+ * (`stats` is [B][*nslabs][cout][2]); the reducers sum slabs in index order.  It depends on the
+ * kernel choice below (the ping-pong kernel writes one slab per wave that shares a column block). */
 int sa_conv_gemm_geometry(int dtype, int cin, int cout, int u, int Lout, int* ntiles, int* nslabs);
-int sa_conv_gemm_set_impl(int pingpong);
+/* Kernel choice of sa_conv_gemm, process-wide.  2 (default): the weight-stationary kernel
+ * (sa_conv_ws.hip) serves the bf16x3 128->128 stride-1 5-tap launches with >= 512 tiles that it
+ * covers (no pro_stats, no second affine, no fused backward epilogue, no normalisation-backward
+ * prologue), the one-tile-per-workgroup kernel everything else -- same geometry and, given the same
+ * inputs, the same output bits.  0: one-tile kernel only.  1: the ping-pong kernel (sa_conv_pp.hip)
+ * for the f32 / bf16x3 policies (opt-in, A/B timing).  sa_conv_pp_set_tile_rows: 0 (policy), 64, 128. */
+int sa_conv_gemm_set_impl(int impl);
 int sa_conv_pp_set_tile_rows(int rows);
 
 /* fp32 master weights -> fragment-major MFMA operand image (K = GEMM reduction channels,

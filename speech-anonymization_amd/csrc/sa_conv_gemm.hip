@@ -553,12 +553,15 @@ extern "C" int sa_conv_gemm_ntiles(int cin, int cout, int u, int Lout) {
 int sa_conv_pp_dispatch(int dtype, int cin, int cout, int sa, int u, const SaConvArgs* a, hipStream_t st);
 int sa_pp_tile_rows(int cin, int cout, int u);
 int sa_pp_share(int cout);
-// sa_conv_gemm_set_impl(2): the 128->128 bf16x3 launches the weight-stationary kernel covers
-// (sa_conv_ws.hip: persistent, one wave per SIMD, weights in registers, rows by LDS-DMA) go there;
+// Kernel choice.  Default (2): the 128->128 bf16x3 launches the weight-stationary kernel covers
+// (sa_conv_ws.hip: persistent, one wave per SIMD, weights in registers, rows by LDS-DMA, epilogue and
+// transform in the MFMA loop's issue gaps) go there when the launch has at least two tiles per CU --
+// 271 / 293 us against 330 / 367 us (plain / forward with cache + statistics, B = 32, r02 profiles);
 // same slab geometry as this file's 64-row tiles, so nothing else changes for the caller.
+// sa_conv_gemm_set_impl(0): this file's kernel only; (1): the ping-pong kernel for f32 / bf16x3.
 bool sa_conv_ws_covers(int dtype, int cin, int cout, int sa, int u, const SaConvArgs* a);
 int sa_conv_ws_dispatch(const SaConvArgs* a, hipStream_t st);
-static int g_use_pp = 0, g_use_ws = 0;
+static int g_use_pp = 0, g_use_ws = 1;
 extern "C" int sa_conv_gemm_set_impl(int impl) {
   if (impl < 0 || impl > 2) return -22;
   g_use_pp = impl == 1;
@@ -632,7 +635,8 @@ extern "C" int sa_conv_gemm(int dtype, int cin, int cout, int sa, int u, const S
   if (!a || !a->x || !a->wp || !a->y || a->B <= 0 || a->Lin <= 0 || a->Lout <= 0) return -22;
   if (a->ep_mode < 0 || a->ep_mode > 2 || (a->ep_mode && !a->ep_x)) return -22;
   if (uses_pp(dtype)) return sa_conv_pp_dispatch(dtype, cin, cout, sa, u, a, st);
-  if (g_use_ws && tile_rows(cin, cout, u) == 64 && sa_conv_ws_covers(dtype, cin, cout, sa, u, a))
+  if (g_use_ws && tile_rows(cin, cout, u) == 64 && sa_conv_ws_covers(dtype, cin, cout, sa, u, a) &&
+      (long)a->B * sa_div_up(a->Lout, 64) >= 512)
     return sa_conv_ws_dispatch(a, st);
   SA_CONV_CASE(32, 64, 2, 1)
   SA_CONV_CASE(64, 64, 1, 1)

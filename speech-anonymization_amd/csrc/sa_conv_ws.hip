@@ -23,7 +23,12 @@
 //   per tile g, per wave:   wait DMA(g) | transform(g) -> planes[g&1] | issue DMA(g+1) |
 //                           epilogue(g-1) from registers | barrier | MFMA(g)
 //
-// Launches it does not cover (pro_stats, the generic two-affine prologue) stay on sa_conv_gemm.hip.
+// Launches it does not cover stay on sa_conv_gemm.hip: pro_stats, the generic two-affine prologue,
+// and the data gradients.  A fused data gradient reads two more fp32 tiles per output tile (the stored
+// forward tensor for the normalisation-backward prologue, and it again + a second gradient in the
+// backward epilogue): 70 KB more LDS or 64 more registers per lane than this structure has left
+// (512 registers: 320 weights, 64 accumulators + their epilogue copy, 24 A fragments, the rest
+// transform state).  The prologue alone (MODE 2) is kept, bit-equal, behind -DSA_WS_PRO2.
 #include <type_traits>
 #include "sa_conv_cfg.h"
 
@@ -35,7 +40,7 @@
 // workgroup's wave 0; no stamp exists in the normal build.
 #ifdef SA_WS_STAMPS
 __device__ unsigned long long sa_ws_dbg[64 * 8];
-#define WS_STAMP(it, i) do { if (lane == 0 && wave == 0 && blockIdx.x == 7 && (it) < 64) { \
+#define WS_STAMP(it, i) do { if (lane_ == 0 && wave_ == 0 && blockIdx.x == 7 && (it) < 64) { \
   unsigned long long t_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); \
   sa_ws_dbg[(it) * 8 + (i)] = t_; } } while (0)
 extern "C" int sa_ws_dbg_read(unsigned long long* out) {
@@ -59,7 +64,7 @@ constexpr int WS_NDMA = WS_ROWS / 2;       // 1-KiB DMA pieces (2 rows each) per
 constexpr int WS_DPW = (WS_NDMA + 3) / 4;  // pieces per wave (waves 0,1: 9; waves 2,3: 8)
 constexpr int WS_RAW_BYTES = WS_ROWS * WS_C * 4;        // one raw fp32 tile
 constexpr int WS_BUF_BYTES = 2 * WS_PLANE * 2;          // one operand buffer (hi + lo planes)
-constexpr int WS_NAGPR_FRAGS = 30;         // (tap, k-step) pairs whose hi + lo weight fragments live in AGPRs (240 of 256)
+constexpr int WS_NAGPR_FRAGS = 32;         // (tap, k-step) pairs whose hi + lo weight fragments live in AGPRs (all 256)
 
 typedef __attribute__((address_space(3))) unsigned char lds_byte;
 
@@ -70,6 +75,56 @@ __device__ static inline void ws_dma16(const void* gsrc, unsigned lds_dst) {
   asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
                : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
 }
+// the same with a uniform base and a 32-bit lane offset (no per-piece vector address arithmetic)
+__device__ static inline void ws_dma16s(const void* gbase, unsigned voff, unsigned lds_dst) {
+  unsigned keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep) : "v"(voff), "s"(gbase), "s"(lds_dst) : "memory");
+}
+
+// stores of the filler slots: uniform base (SGPR pair) + 32-bit lane offset, exactly one instruction
+// (hipcc rebuilds a 64-bit vector address per store otherwise); not counted by hipcc's vmcnt
+// bookkeeping -- the kernel waits with its own s_waitcnt vmcnt(0)
+__device__ static inline void ws_store_b32(void* base, unsigned voff, float v) {
+  asm volatile("global_store_dword %0, %1, %2" :: "v"(voff), "v"(v), "s"(base) : "memory");
+}
+__device__ static inline void ws_store_b64(void* base, unsigned voff, uint2 v) {
+  asm volatile("global_store_dwordx2 %0, %1, %2" :: "v"(voff), "v"(v), "s"(base) : "memory");
+}
+
+// (bf16(a), bf16(b)) in one instruction, RNE like the cast (hipcc converts one value per
+// instruction and assembles the pair with shifts and ors)
+__device__ static inline unsigned ws_cvt_pk_bf16(float a, float b) {
+  unsigned r;
+  asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+
+template <int I, int N, class F>
+__device__ __forceinline__ void ws_static_for(F&& f) {
+  if constexpr (I < N) {
+    f(std::integral_constant<int, I>{});
+    ws_static_for<I + 1, N>(f);
+  }
+}
+
+// Filler slots.  With one wave per SIMD a wave issues one instruction (of any kind) per 4 cycles, a
+// 32x32x16 MFMA holds the matrix pipe for 32: the MFMA loop of a tile is 120 asm statements of two
+// MFMAs, and the gap after statement n ("slot n") takes about a dozen instructions of OTHER tiles'
+// work without delaying statement n+1 -- 1 920 issue slots per tile, 240 MFMAs + 160 fragment reads
+// of its own.  So the fillers are written to the instruction: lane offsets, LDS addresses and store
+// offsets are set up once per kernel / tile, every slot is base + immediate.
+//   slots 0..31   epilogue of the previous tile, one accumulator register (two 128-byte row
+//                 segments) per slot; slot 32: its statistics
+//   slot  TS-1    s_waitcnt vmcnt(0): the DMA of the next tile (issued a whole loop ago) and the
+//                 stores above (a microsecond ago) have landed; first raw read
+//   slots TS+7j.. transform of piece j of the next tile: 4 slots of arithmetic (one channel each),
+//                 split + operand-plane writes, operand-cache store, refill DMA of the piece for
+//                 the tile after next
+// Tiles at the ends of an utterance (rows outside it: clamped DMA addresses, zeroed operand rows,
+// ownership checks) and partial output tiles take general, masked versions of the same slots.
+constexpr int WS_FT = 114;                 // first transform slot
+static_assert(WS_FT + 14 * WS_DPW <= 240, "transform slots");
 
 // MODE: 0 no transform, 1 affine (per utterance, channel) + x*sigmoid(x), 2 normalisation-backward
 // prologue (nb_*: d y = c1*dz + c2*y + c3 [* (y > 0)] over two input tensors)
@@ -82,8 +137,8 @@ void sa_conv_ws_kernel(SaConvArgs a, int tiles_per_wg, int total_tiles) {
   bf16_t* const planes = reinterpret_cast<bf16_t*>(smem);
   unsigned char* const raw = smem + 2 * WS_BUF_BYTES;
   const unsigned raw_lds = (unsigned)(uintptr_t)(lds_byte*)raw;
-  const int tid = threadIdx.x, lane_ = tid & 63, lane = lane_;
-  const int wave_ = __builtin_amdgcn_readfirstlane(tid >> 6), wave = wave_;
+  const int tid = threadIdx.x, lane_ = tid & 63;
+  const int wave_ = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int first = blockIdx.x * tiles_per_wg;
   int last = first + tiles_per_wg;
   if (last > total_tiles) last = total_tiles;
@@ -95,28 +150,61 @@ void sa_conv_ws_kernel(SaConvArgs a, int tiles_per_wg, int total_tiles) {
     const bf16x8* wp = reinterpret_cast<const bf16x8*>(a.wp);
 #pragma unroll
     for (int t = 0; t < WS_NTAPS; ++t) {
-      const bf16x8* wt = wp + ((size_t)a.taps.widx[0][t] * WS_KSTEPS * 4 + wave) * 64 + lane;
+      const bf16x8* wt = wp + ((size_t)a.taps.widx[0][t] * WS_KSTEPS * 4 + wave_) * 64 + lane_;
 #pragma unroll
       for (int k = 0; k < WS_KSTEPS; ++k) {
         Bh[t][k] = wt[(size_t)k * 4 * 64];
         Bl[t][k] = wt[(size_t)a.wlo_off + (size_t)k * 4 * 64];
       }
       // one tap at a time, moved to its AGPR home before the next tap is fetched (all 80 loads at
-      // once would need 320 VGPRs)
+      // once would need 320 VGPRs).  The empty asm also makes hipcc wait for the loads HERE: a value
+      // still "pending" at the loop header gets its s_waitcnt vmcnt(0) inside the loop, in front of
+      // every use, and that wait would drain the LDS-DMA in flight there.
 #pragma unroll
-      for (int k = 0; k < WS_KSTEPS; ++k)
+      for (int k = 0; k < WS_KSTEPS; ++k) {
         if (t * WS_KSTEPS + k < WS_NAGPR_FRAGS) asm volatile("" : "+a"(Bh[t][k]), "+a"(Bl[t][k]));
+        else asm volatile("" : "+v"(Bh[t][k]), "+v"(Bl[t][k]));
+      }
       __builtin_amdgcn_sched_barrier(0);
     }
   }
-  const int col = wave * 32 + (lane & 31);
-  const float bv = a.bias ? a.bias[col] : 0.0f;
-  const int ch = (lane & 31) * 4;                          // this lane's 4 channels in the transform
+  float bv = a.bias ? a.bias[wave_ * 32 + (lane_ & 31)] : 0.0f;
+  float relu_floor = a.relu ? 0.0f : -__builtin_inff();     // max(v, -inf) = v: no branch in the slot
+  const bool has_stats = a.stats != nullptr, has_ao = a.a_out != nullptr;
+
+  // ---- lane constants of the filler slots (made opaque so that hipcc keeps THESE and derives the
+  // per-slot addresses from them by immediates, instead of hoisting one address chain per slot) ----
+  const int half_ = lane_ >> 5, l31_ = lane_ & 31;
+  // this wave's piece j is piece i = wave + 4j of the tile: rows 2i + half, i.e. row (2 wave + half) + 8j
+  unsigned row0 = 2 * wave_ + half_;
+  unsigned dma_off = row0 * (WS_C * 4) + l31_ * 16;        // byte offset in the row block of a tile (x, nb_x): + j*4096
+  unsigned raw_off = wave_ * 1024 + lane_ * 16;            // byte offset in the raw tile: + j*4096
+  unsigned pl_off = (row0 * WS_PITCH + l31_ * 4) * 2;      // byte offset in an operand plane: + j*8*PITCH*2
+  unsigned ao_off = (row0 * WS_C + l31_ * 4) * 2;          // byte offset in the a_out row block: + j*8*C*2
+  unsigned y_off = (4 * half_ * WS_C + wave_ * 32 + l31_) * 4;   // byte offset in the y row block: + ro*512
+  unsigned st_off = (wave_ * 32 + l31_) * 8;               // byte offset of this lane's column in a statistics slab
+  unsigned swap_off = (lane_ ^ 32) * 4;                    // ds_bpermute address of the lane in the other half
+  asm volatile("" : "+v"(bv), "+v"(relu_floor), "+v"(row0), "+v"(dma_off), "+v"(raw_off), "+v"(pl_off), "+v"(ao_off), "+v"(y_off),
+               "+v"(st_off), "+v"(swap_off));
+
+#define WS_IDS int lane = lane_, wave = wave_; asm volatile("" : "+v"(lane), "+s"(wave)); (void)wave; (void)lane
+
+  // tile index -> (utterance, tile of the utterance) and what the slots need of it
+  struct Tile { int b, tile; };
+  auto tile_of = [&](int t) { Tile r; r.b = t / a.ntiles; r.tile = t - r.b * a.ntiles; return r; };
+  auto next_tile = [&](Tile T) { Tile r; const bool wrap = T.tile + 1 == a.ntiles; r.b = wrap ? T.b + 1 : T.b; r.tile = wrap ? 0 : T.tile + 1; return r; };
+  // rows outside the utterance among the 68 staged ones, or the trailing rows it owns beyond its 64
+  auto is_edge = [&](Tile T) {
+    const int g0 = T.tile * WS_TM + a.rowmin;
+    return g0 < 0 || g0 + WS_ROWS > a.Lin || T.tile == a.ntiles - 1;
+  };
 
   // per-utterance transform constants (reloaded when the tile range crosses an utterance)
   float s1[4], t1[4], k1[4], k2[4], k3[4];
   int cur_b = -1;
   auto load_consts = [&](int b) {
+    WS_IDS;
+    const int ch = (lane & 31) * 4;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       if constexpr (MODE == 1) {
@@ -128,242 +216,473 @@ void sa_conv_ws_kernel(SaConvArgs a, int tiles_per_wg, int total_tiles) {
         k1[j] = a.nb_c1[q]; k2[j] = a.nb_c2[q]; k3[j] = a.nb_c3[q];
       }
     }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {                          // waited for here, not in the filler slots
+      if constexpr (MODE == 1) asm volatile("" : "+v"(s1[j]), "+v"(t1[j]));
+      if constexpr (PRO2) asm volatile("" : "+v"(k1[j]), "+v"(k2[j]), "+v"(k3[j]));
+    }
     cur_b = b;
   };
 
-  // ---- LDS-DMA of the rows of tile t (this wave's pieces) ----
-  // (lane / wave ids are made opaque per call: hipcc otherwise hoists the address chains of every
-  // piece, row and accumulator register out of the tile loop and keeps -- spills -- them all)
-  auto issue_dma = [&](int t) {
-    int lane = lane_, wave = wave_;
-    asm volatile("" : "+v"(lane), "+s"(wave));
-    const int b = t / a.ntiles, tile = t % a.ntiles;
-    const int gbase = tile * WS_TM + a.rowmin;
-    const char* xb = reinterpret_cast<const char*>(a.x) + (size_t)b * a.Lin * (WS_C * 4) + (lane & 31) * 16;
-    const char* x2 = PRO2 ? reinterpret_cast<const char*>(a.nb_x) + (size_t)b * a.Lin * (WS_C * 4) + (lane & 31) * 16 : nullptr;
-#pragma unroll
-    for (int j = 0; j < WS_DPW; ++j) {
-      const int i = wave + 4 * j;                          // piece: rows 2i, 2i+1
-      if (i < WS_NDMA) {
-        int g = gbase + 2 * i + (lane >> 5);
-        g = g < 0 ? 0 : (g >= a.Lin ? a.Lin - 1 : g);      // rows outside the utterance: any valid address (zeroed in the transform)
-        ws_dma16(xb + (size_t)g * (WS_C * 4), raw_lds + i * 1024);
-        if constexpr (PRO2) ws_dma16(x2 + (size_t)g * (WS_C * 4), raw_lds + WS_RAW_BYTES + i * 1024);
+  // ---- LDS-DMA of piece j of this wave (rows 2i, 2i+1; i = wave + 4j) of tile T ----
+  // uniform per-tile bases of the slots (set once per iteration, opaque: hipcc otherwise recomputes
+  // them -- two scalar multiplies and a 64-bit add chain -- in every slot)
+  const char* xbase_d = nullptr; const char* x2base_d = nullptr;    // rows of the DMA tile (x, nb_x)
+  char* aobase_t = nullptr;                                          // a_out rows of the transform tile
+  char* ybase_e = nullptr;                                           // y rows of the epilogue tile
+  auto row_block = [&](const void* p, int b, int L, int row, int row_bytes) {
+    const char* r = reinterpret_cast<const char*>(p) + (long)(b * L + row) * row_bytes;   // B*L rows < 2^31 (checked at launch)
+    asm volatile("" : "+s"(r));
+    return r;
+  };
+  auto dma_piece = [&](Tile T, bool edge, int j, int part = 2) {
+    const int i = wave_ + 4 * j;
+    if (j == WS_DPW - 1 && i >= WS_NDMA) return;
+    const int g0 = T.tile * WS_TM + a.rowmin;
+    if (!edge) {
+      if (part != 1) ws_dma16s(xbase_d + j * 4096, dma_off, raw_lds + i * 1024);
+      if constexpr (PRO2) {
+        if (part != 0) ws_dma16s(x2base_d + j * 4096, dma_off, raw_lds + WS_RAW_BYTES + i * 1024);
       }
+    } else {
+      WS_IDS;
+      int g = g0 + 2 * i + (lane >> 5);
+      g = g < 0 ? 0 : (g >= a.Lin ? a.Lin - 1 : g);        // rows outside the utterance: any valid address (zeroed in the transform)
+      const size_t off = ((size_t)T.b * a.Lin + g) * (WS_C * 4) + (lane & 31) * 16;
+      ws_dma16(reinterpret_cast<const char*>(a.x) + off, raw_lds + i * 1024);
+      if constexpr (PRO2) ws_dma16(reinterpret_cast<const char*>(a.nb_x) + off, raw_lds + WS_RAW_BYTES + i * 1024);
     }
   };
 
-  // ---- transform of tile t: raw (this wave's own pieces) -> operand planes[t & 1] ----
-  float csum[4];
-  auto transform = [&](int t, int it) {
-    int lane = lane_, wave = wave_;
-    asm volatile("" : "+v"(lane), "+s"(wave));
-    const int ch = (lane & 31) * 4;
-    const int b = t / a.ntiles, tile = t % a.ntiles, m0 = tile * WS_TM;
-    if (MODE != 0 && b != cur_b) load_consts(b);
-    const int gbase = m0 + a.rowmin;
-    const int own_lo = m0;
-    int own_hi = tile == a.ntiles - 1 ? a.Lin : m0 + WS_TM;
-    if (own_hi > a.Lin) own_hi = a.Lin;
-    bf16_t* dstb = planes + (size_t)(it & 1) * 2 * WS_PLANE + ch;
-    bf16_t* ao = a.a_out ? reinterpret_cast<bf16_t*>(a.a_out) + (size_t)b * a.Lin * WS_C + ch : nullptr;
-#pragma unroll
-    for (int j = 0; j < 4; ++j) csum[j] = 0.0f;
-    // the pieces go through registers one at a time, the next one's LDS reads in flight behind the
-    // current one's arithmetic (pinned: left alone hipcc reads all nine pieces up front -- 72
-    // registers in the PRO2 form -- and spills weight fragments to make room)
-    f32x4 vx[2], vy[2];
-    auto read_piece = [&](int slot, int j) {
-      const int i = wave + 4 * j;
-      vx[slot] = *reinterpret_cast<const f32x4*>(raw + i * 1024 + lane * 16);
-      if constexpr (PRO2) vy[slot] = *reinterpret_cast<const f32x4*>(raw + WS_RAW_BYTES + i * 1024 + lane * 16);
-    };
-    read_piece(0, 0);
-#pragma unroll
-    for (int j = 0; j < WS_DPW; ++j) {
-      const int i = wave + 4 * j;
-      if (j + 1 < WS_DPW) read_piece((j + 1) & 1, j + 1);   // (piece 34/35 of waves 2, 3: inside the raw tile of the next tensor / scratch, unused)
-      __builtin_amdgcn_sched_barrier(0);
-      if (i < WS_NDMA) {
-        const int r = 2 * i + (lane >> 5), g = gbase + r;
-        float f[4];
-        const f32x4 v = vx[j & 1];
-        f[0] = v[0]; f[1] = v[1]; f[2] = v[2]; f[3] = v[3];
-        const bool in = g >= 0 && g < a.Lin;
-        if constexpr (MODE == 1) {
-#pragma unroll
-          for (int q = 0; q < 4; ++q) f[q] = sa_swish(fmaf(f[q], s1[q], t1[q]));
-        }
-        if constexpr (PRO2) {
-          const f32x4 y = vy[j & 1];
-          const bool own = g >= own_lo && g < own_hi;
-#pragma unroll
-          for (int q = 0; q < 4; ++q) {
-            float u = fmaf(k1[q], f[q], fmaf(k2[q], y[q], k3[q]));
-            if (a.nb_relu_mask && !(y[q] > 0.0f)) u = 0.0f;
-            f[q] = u;
-            if (own) csum[q] += u;
-          }
-        }
-        if (!in) { f[0] = 0.0f; f[1] = 0.0f; f[2] = 0.0f; f[3] = 0.0f; }
-        uint2 hi, lo;
-        sa_split4(f, hi, lo);
-        bf16_t* dst = dstb + (size_t)r * WS_PITCH;
-        *reinterpret_cast<uint2*>(dst) = hi;
-        *reinterpret_cast<uint2*>(dst + WS_PLANE) = lo;
-        // bf16 operand cache for sa_wgrad: the hi values of the rows this tile owns
-        if (ao && g >= own_lo && g < own_hi) *reinterpret_cast<uint2*>(ao + (size_t)g * WS_C) = hi;
+  // ---- transform of a piece, in sub-steps (each small enough for one filler slot) ----
+  f32x4 vx[1], vy[1];                                      // the raw piece being transformed (the next one is read as soon as stage 0 has consumed it)
+  float f[4], csum[4];
+#ifdef SA_WS_DBG_BITS
+  float dbgv[4];                                           // diagnostic: a stage value whose low 16 bits go to a_out
+#endif
+  uint2 phi, plo;                                          // hi / lo bf16 quadruples of the piece
+  unsigned pl_cur = 0;                                     // LDS byte offset of this lane's first row in the transform tile's buffer
+  auto piece_read = [&](int j, int part = 2) {              // 0: x, 1: nb_x (PRO2), 2: both
+    if (j == WS_DPW - 1 && wave_ + 4 * j >= WS_NDMA) return;
+    if (part != 1) vx[0] = *reinterpret_cast<const f32x4*>(raw + (raw_off + j * 4096));
+    if constexpr (PRO2) {
+      if (part != 0) vy[0] = *reinterpret_cast<const f32x4*>(raw + (raw_off + WS_RAW_BYTES + j * 4096));
+    }
+  };
+  auto own_range = [&](Tile T, int& lo, int& hi) {
+    lo = T.tile * WS_TM;
+    hi = T.tile == a.ntiles - 1 ? a.Lin : lo + WS_TM;
+    if (hi > a.Lin) hi = a.Lin;
+  };
+  // is this lane's row of piece j one the tile owns (operand cache, column sums)?  interior tiles:
+  // every piece but the two halo pieces (i = 0: rows -2, -1; i = 33: rows 64, 65), a wave-uniform test
+  auto owns = [&](Tile T, bool edge, int j) -> bool {
+    if (!edge) return (j != 0 || wave_ != 0) && (j != WS_DPW - 1 || wave_ != (WS_NDMA - 1) % 4);
+    int lo, hi;
+    own_range(T, lo, hi);
+    const int g = T.tile * WS_TM + a.rowmin + (int)row0 + 8 * j;
+    return g >= lo && g < hi;
+  };
+  // hi = bf16(v), lo = bf16(v - hi) of a channel pair (same roundings as sa_split4)
+  auto split_pair = [&](float a0, float a1, unsigned& hi, unsigned& lo) {
+    // (opaque: with the product z * r that formed a0 in the same block, hipcc contracts a0 - hi into
+    // fma(z, r, -hi), i.e. splits the UNROUNDED product -- one bf16 ulp of lo off the one-tile kernel
+    // in 1.4 % of the elements, and dependent on which path staged the tile)
+    asm volatile("" : "+v"(a0), "+v"(a1));
+    hi = ws_cvt_pk_bf16(a0, a1);
+    lo = ws_cvt_pk_bf16(a0 - __uint_as_float(hi << 16), a1 - __uint_as_float(hi & 0xffff0000u));
+  };
+  auto piece_elem = [&](Tile T, bool edge, int j, int q) {            // channel q of the lane's four
+    if (j == WS_DPW - 1 && wave_ + 4 * j >= WS_NDMA) return;
+    float v = vx[0][q];
+    if constexpr (MODE == 1) {                             // the very operations of piece_stage: a row's operand
+      const float zz = fmaf(v, s1[q], t1[q]);              // must not depend on which path staged it
+#if defined(SA_WS_EXP2)
+      v = zz;
+#elif defined(SA_WS_EXP3)
+      v = __builtin_amdgcn_exp2f(zz * -1.4426950408889634f);
+#elif defined(SA_WS_DBG_BITS)
+      {
+        const float e_ = __builtin_amdgcn_exp2f(zz * -1.4426950408889634f), d_ = 1.0f + e_, r_ = __builtin_amdgcn_rcpf(d_);
+        v = zz * r_;
+        dbgv[q] = SA_WS_DBG_BITS == 1 ? zz : SA_WS_DBG_BITS == 2 ? e_ : SA_WS_DBG_BITS == 3 ? d_ : SA_WS_DBG_BITS == 4 ? r_ : v;
       }
-      __builtin_amdgcn_sched_barrier(0);
+#else
+      v = zz * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(zz * -1.4426950408889634f));
+#endif
     }
     if constexpr (PRO2) {
+      const float y = vy[0][q];
+      v = fmaf(k1[q], v, fmaf(k2[q], y, k3[q]));
+      if (a.nb_relu_mask) v = y > 0.0f ? v : 0.0f;
+      if (a.nb_colsum && owns(T, edge, j)) csum[q] += v;
+    }
+    if (edge) {                                            // rows outside the utterance are zero operands
+      const int g = T.tile * WS_TM + a.rowmin + (int)row0 + 8 * j;
+      if (!(g >= 0 && g < a.Lin)) v = 0.0f;
+    }
+    f[q] = v;
+    if (q == 1) split_pair(f[0], f[1], phi.x, plo.x);
+    if (q == 3) split_pair(f[2], f[3], phi.y, plo.y);
+  };
+  // The same transform as piece_elem for an interior tile, cut by STAGE instead of by channel: a
+  // slot then holds four independent instructions per stage instead of one six-deep dependent chain
+  // (with one wave per SIMD nothing else covers the latency of a dependent VALU / transcendental op).
+  float z[4], w[4];
+  auto piece_stage = [&](Tile T, int j, int st, int h) {    // h: channel pair (2h, 2h+1) of the lane's four
+    if (j == WS_DPW - 1 && wave_ + 4 * j >= WS_NDMA) return;
+#pragma unroll
+    for (int q = 2 * h; q < 2 * h + 2; ++q) {
+      if constexpr (MODE == 0) {
+        if (st == 0) f[q] = vx[0][q];
+      } else if constexpr (MODE == 1) {                    // x*sigmoid(x), the operations of sa_swish
+#if defined(SA_WS_EXP2)                                    // diagnostic: affine only
+        if (st == 0) f[q] = fmaf(vx[0][q], s1[q], t1[q]);
+#elif defined(SA_WS_EXP3)                                  // diagnostic: affine + exp2 only
+        if (st == 0) f[q] = __builtin_amdgcn_exp2f(fmaf(vx[0][q], s1[q], t1[q]) * -1.4426950408889634f);
+#elif defined(SA_WS_EXP1)
+        if (st == 0) { const float zz = fmaf(vx[0][q], s1[q], t1[q]); f[q] = zz * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(zz * -1.4426950408889634f)); }
+#else
+        if (st == 0) { z[q] = fmaf(vx[0][q], s1[q], t1[q]); w[q] = z[q] * -1.4426950408889634f; }
+        if (st == 1) w[q] = 1.0f + __builtin_amdgcn_exp2f(w[q]);
+#if defined(SA_WS_DBG_BITS)
+        if (st == 2) {
+          const float r_ = __builtin_amdgcn_rcpf(w[q]);
+          f[q] = z[q] * r_;
+          dbgv[q] = SA_WS_DBG_BITS == 1 ? z[q] : SA_WS_DBG_BITS == 2 ? w[q] - 1.0f : SA_WS_DBG_BITS == 3 ? w[q] : SA_WS_DBG_BITS == 4 ? r_ : f[q];
+        }
+#elif defined(SA_WS_EXP4)
+        if (st == 2) { w[q] = __builtin_amdgcn_rcpf(w[q]); if (q == 2 * h + 1) { asm volatile("s_nop 3" : "+v"(w[2 * h]), "+v"(w[2 * h + 1])); f[2 * h] = z[2 * h] * w[2 * h]; f[q] = z[q] * w[q]; } }
+#else
+        if (st == 2) f[q] = z[q] * __builtin_amdgcn_rcpf(w[q]);
+#endif
+#endif
+      } else {
+        if (st == 0) { z[q] = fmaf(k2[q], vy[0][q], k3[q]); f[q] = fmaf(k1[q], vx[0][q], z[q]); }
+        if (st == 1) { if (a.nb_relu_mask) f[q] = vy[0][q] > 0.0f ? f[q] : 0.0f; }
+        if (st == 2) { if (a.nb_colsum && owns(T, false, j)) csum[q] += f[q]; }
+      }
+    }
+    if (st == 3) {
+      if (h == 0) split_pair(f[0], f[1], phi.x, plo.x);
+      else split_pair(f[2], f[3], phi.y, plo.y);
+    }
+  };
+  auto piece_write = [&](int j, int part = 2) {             // operand planes of the transform tile (0 hi, 1 lo, 2 both)
+    if (j == WS_DPW - 1 && wave_ + 4 * j >= WS_NDMA) return;
+    unsigned char* dst = smem + (pl_cur + j * (8 * WS_PITCH * 2));
+    if (part != 1) *reinterpret_cast<uint2*>(dst) = phi;
+    if (part != 0) *reinterpret_cast<uint2*>(dst + WS_PLANE * 2) = plo;
+  };
+  auto piece_cache = [&](Tile T, bool edge, int j) {          // bf16 operand cache for sa_wgrad: hi values of the owned rows
+    if (j == WS_DPW - 1 && wave_ + 4 * j >= WS_NDMA) return;
+#if defined(SA_WS_DBG_BITS)
+    if (has_ao && owns(T, edge, j))
+      ws_store_b64(aobase_t + j * (8 * WS_C * 2), ao_off,
+                   make_uint2((__float_as_uint(dbgv[0]) & 0xffffu) | (__float_as_uint(dbgv[1]) << 16),
+                              (__float_as_uint(dbgv[2]) & 0xffffu) | (__float_as_uint(dbgv[3]) << 16)));
+#elif defined(SA_WS_DBG_LO)                                // diagnostic build: the lo plane instead of the hi one
+    if (has_ao && owns(T, edge, j)) ws_store_b64(aobase_t + j * (8 * WS_C * 2), ao_off, plo);
+#else
+    if (has_ao && owns(T, edge, j)) ws_store_b64(aobase_t + j * (8 * WS_C * 2), ao_off, phi);
+#endif
+  };
+  auto colsum_put = [&](int it) {                           // PRO2: this wave's column sums -> LDS (summed after the barrier)
+    if constexpr (PRO2) {
       if (a.nb_colsum) {
-        // column sums of d y over the owned rows: fold the two row halves of the wave; one LDS slot
-        // per wave, summed after the tile barrier
+        WS_IDS;
         float* colred = reinterpret_cast<float*>(raw + 2 * WS_RAW_BYTES) + (size_t)(it & 1) * 4 * WS_C;
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
           const float v = csum[q] + __shfl_xor(csum[q], 32, 64);
-          if (lane < 32) colred[wave * WS_C + ch + q] = v;
+          if (lane < 32) colred[wave * WS_C + (lane & 31) * 4 + q] = v;
+          csum[q] = 0.0f;
         }
       }
     }
   };
-
-  // ---- epilogue of tile t from the accumulator registers ----
-  f32x16 acc[2];
-  auto epilogue = [&](int t) {
-    int lane = lane_, wave = wave_;
-    asm volatile("" : "+v"(lane), "+s"(wave));
-    const int col = wave * 32 + (lane & 31);
-    const int b = t / a.ntiles, tile = t % a.ntiles, m0 = tile * WS_TM;
-    // uniform base + one 32-bit lane offset: the 32 stores of a tile are then immediate offsets from
-    // 8 registers (as 64-bit per-store addresses they cost 64 registers, and weight fragments spill)
-    char* ybase = reinterpret_cast<char*>(a.y) + ((size_t)b * a.Lout + m0) * (WS_C * 4);
-    const unsigned loff = ((4 * (lane >> 5)) * WS_C + col) * 4;
-    float ssum = 0.0f, ssq = 0.0f;
-    auto body = [&](auto full_c) {
-      constexpr bool FULL = decltype(full_c)::value;
-#pragma unroll
-      for (int m = 0; m < 2; ++m) {
-#pragma unroll
-        for (int i = 0; i < 16; ++i) {
-          const int ro = m * 32 + (i & 3) + 8 * (i >> 2);           // row in the tile, before the lane half's +4
-          float val = acc[m][i] + bv;
-          if (a.relu) val = fmaxf(val, 0.0f);
-          if (FULL || m0 + ro + 4 * (lane >> 5) < a.Lout) {
-            *reinterpret_cast<float*>(ybase + (loff + (unsigned)ro * (WS_C * 4))) = val;
-            ssum += val; ssq = fmaf(val, val, ssq);
-          }
-        }
-        __builtin_amdgcn_sched_barrier(0);
-      }
-    };
-    const bool full = m0 + WS_TM <= a.Lout;                // uniform
-    if ((SA_ABL & 4) && a.B > 0) {
-      if (acc[0][0] + acc[1][5] == 1.2345e-33f) ybase[loff] = 0;
-    } else if (full) {
-      body(std::true_type{});
-    } else {
-      body(std::false_type{});
-    }
-    if (a.stats) {
-      ssum += __shfl_xor(ssum, 32, 64);
-      ssq += __shfl_xor(ssq, 32, 64);
-      if (lane < 32) {
-        float* dst = a.stats + (((size_t)b * a.ntiles + tile) * WS_C + col) * 2;
-        dst[0] = ssum; dst[1] = ssq;
-      }
-    }
-  };
-
-  // ---- MFMA loop of the tile staged in planes[it & 1] ----
-  int toff[WS_NTAPS];
-#pragma unroll
-  for (int t = 0; t < WS_NTAPS; ++t) toff[t] = (a.taps.off[0][t] - a.rowmin) * WS_PITCH;
-  // The MFMAs are inline asm so that the weight fragments are AGPR operands where they live (left to
-  // itself hipcc parks them in AGPRs and copies each one to VGPRs in front of every use, with one
-  // A-fragment buffer and lgkmcnt(0) per MFMA).  The first 30 (tap, k-step) pairs (60 fragments) take 240 of the 256 AGPRs
-  // (hipcc needs a few as spill / reload temporaries), the other 10 pairs stay in VGPRs.  Hazards (cdna_hip_programming.md 5.7 item 2): an accumulate chain needs no wait
-  // states; the A fragments come from ds_read (waited for by hipcc, which sees the operand); the
-  // accumulators are read by VALU code only after the s_nop block below.
-  auto mfma_tile = [&](int it) {
-    int lane = lane_;
-    asm volatile("" : "+v"(lane));
-    const bf16_t* ab = planes + (size_t)(it & 1) * 2 * WS_PLANE + (lane & 31) * WS_PITCH + (lane >> 5) * 8;
-    constexpr int NS = WS_NTAPS * WS_KSTEPS;
-    bf16x8 ah[2][2], al[2][2];                             // [slot][m-tile]: one step ahead of the MFMAs
-    auto load_a = [&](int slot, int s) {
-      const int t = s / WS_KSTEPS, k = s % WS_KSTEPS;
-#pragma unroll
-      for (int m = 0; m < 2; ++m) {
-        const bf16_t* ap = ab + toff[t] + m * 32 * WS_PITCH + k * 16;
-        ah[slot][m] = *reinterpret_cast<const bf16x8*>(ap);
-        al[slot][m] = *reinterpret_cast<const bf16x8*>(ap + WS_PLANE);
-      }
-    };
-    load_a(0, 0);
-#pragma unroll
-    for (int s = 0; s < NS; ++s) {
-      if (s + 1 < NS) load_a((s + 1) & 1, s + 1);
-      __builtin_amdgcn_sched_barrier(0);
-      const int t = s / WS_KSTEPS, k = s % WS_KSTEPS, sl = s & 1;
-      if constexpr ((SA_ABL & 1) != 0) {
-        asm volatile("" :: "v"(ah[sl][0]), "v"(al[sl][0]), "v"(ah[sl][1]), "v"(al[sl][1]));
-      } else if (s == 0) {
-        asm volatile("v_mfma_f32_32x32x16_bf16 %0, %2, %4, 0\n\tv_mfma_f32_32x32x16_bf16 %1, %3, %4, 0"
-                     : "=&v"(acc[0]), "=&v"(acc[1]) : "v"(al[sl][0]), "v"(al[sl][1]), "a"(Bh[0][0]));
-        asm volatile("v_mfma_f32_32x32x16_bf16 %0, %2, %4, %0\n\tv_mfma_f32_32x32x16_bf16 %1, %3, %4, %1"
-                     : "+v"(acc[0]), "+v"(acc[1]) : "v"(ah[sl][0]), "v"(ah[sl][1]), "a"(Bl[0][0]));
-        asm volatile("v_mfma_f32_32x32x16_bf16 %0, %2, %4, %0\n\tv_mfma_f32_32x32x16_bf16 %1, %3, %4, %1"
-                     : "+v"(acc[0]), "+v"(acc[1]) : "v"(ah[sl][0]), "v"(ah[sl][1]), "a"(Bh[0][0]));
-      } else if (t * WS_KSTEPS + k < WS_NAGPR_FRAGS) {
-        asm volatile("v_mfma_f32_32x32x16_bf16 %0, %2, %4, %0\n\tv_mfma_f32_32x32x16_bf16 %1, %3, %4, %1"
-                     : "+v"(acc[0]), "+v"(acc[1]) : "v"(al[sl][0]), "v"(al[sl][1]), "a"(Bh[t][k]));
-        asm volatile("v_mfma_f32_32x32x16_bf16 %0, %2, %4, %0\n\tv_mfma_f32_32x32x16_bf16 %1, %3, %4, %1"
-                     : "+v"(acc[0]), "+v"(acc[1]) : "v"(ah[sl][0]), "v"(ah[sl][1]), "a"(Bl[t][k]));
-        asm volatile("v_mfma_f32_32x32x16_bf16 %0, %2, %4, %0\n\tv_mfma_f32_32x32x16_bf16 %1, %3, %4, %1"
-                     : "+v"(acc[0]), "+v"(acc[1]) : "v"(ah[sl][0]), "v"(ah[sl][1]), "a"(Bh[t][k]));
-      } else {
-        asm volatile("v_mfma_f32_32x32x16_bf16 %0, %2, %4, %0\n\tv_mfma_f32_32x32x16_bf16 %1, %3, %4, %1"
-                     : "+v"(acc[0]), "+v"(acc[1]) : "v"(al[sl][0]), "v"(al[sl][1]), "v"(Bh[t][k]));
-        asm volatile("v_mfma_f32_32x32x16_bf16 %0, %2, %4, %0\n\tv_mfma_f32_32x32x16_bf16 %1, %3, %4, %1"
-                     : "+v"(acc[0]), "+v"(acc[1]) : "v"(ah[sl][0]), "v"(ah[sl][1]), "v"(Bl[t][k]));
-        asm volatile("v_mfma_f32_32x32x16_bf16 %0, %2, %4, %0\n\tv_mfma_f32_32x32x16_bf16 %1, %3, %4, %1"
-                     : "+v"(acc[0]), "+v"(acc[1]) : "v"(ah[sl][0]), "v"(ah[sl][1]), "v"(Bh[t][k]));
-      }
-      __builtin_amdgcn_sched_barrier(0);
-    }
-    // MFMA result -> VALU reader wait states (the epilogue runs after the next transform anyway)
-    asm volatile("s_nop 15\n\ts_nop 15" : "+v"(acc[0]), "+v"(acc[1]));
-  };
-
-  // ================= the tile walk =================
-  issue_dma(first);
-  for (int t = first, it = 0; t <= last; ++t, ++it) {
-    WS_STAMP(it, 0);
-    if (t < last) {
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // DMA(t) has landed (issued one MFMA loop ago)
-      WS_STAMP(it, 1);
-      transform(t, it);
-      WS_STAMP(it, 2);
-      if (t + 1 < last) issue_dma(t + 1);                  // this wave's raw pieces are consumed: refill them
-    }
-    if (t > first) epilogue(t - 1);
-    WS_STAMP(it, 3);
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();                          // planes[it & 1] complete; planes[(it+1) & 1] free
-    WS_STAMP(it, 4);
+  auto colsum_out = [&](int t, int it) {                    // after the barrier that follows colsum_put(it)
     if constexpr (PRO2) {
-      if (t < last && a.nb_colsum && tid < WS_C) {
+      if (a.nb_colsum && tid < WS_C) {
         const float* colred = reinterpret_cast<const float*>(raw + 2 * WS_RAW_BYTES) + (size_t)(it & 1) * 4 * WS_C;
         a.nb_colsum[(size_t)t * WS_C + tid] =
             (colred[tid] + colred[WS_C + tid]) + (colred[2 * WS_C + tid] + colred[3 * WS_C + tid]);
       }
     }
-    if (t < last) mfma_tile(it);
-    WS_STAMP(it, 5);
+  };
+
+  // ---- epilogue of a tile from the (copied) accumulator registers, one register per call ----
+  f32x16 acc[2], accp[2];
+  float ssum = 0.0f, ssq = 0.0f;
+  auto epi_form = [&](int n) {                              // n = 16 m + i: bias (+ReLU) of one accumulator register
+    float val = accp[n >> 4][n & 15] + bv;
+    asm("v_max_f32 %0, %0, %1" : "+v"(val) : "v"(relu_floor));      // (fmaxf canonicalises both operands first)
+    return val;
+  };
+  float eval = 0.0f;                                        // the value the NEXT slot stores (formed one slot ahead)
+  auto epi_store = [&](int n) {                             // slot form, full tiles: the store of value n
+    const int m = n >> 4, i = n & 15;
+    const int ro = m * 32 + (i & 3) + 8 * (i >> 2);         // row in the tile, before the lane half's +4
+    ws_store_b32(ybase_e + ro * (WS_C * 4), y_off, eval);
+  };
+  auto epi_accum = [&](int n) {                             // ... its statistics, and value n+1 formed
+    // (asm: hipcc otherwise sinks all 32 accumulations into the statistics slot, behind its branch)
+    asm volatile("v_add_f32 %0, %0, %2\n\tv_fmac_f32 %1, %2, %2" : "+v"(ssum), "+v"(ssq) : "v"(eval));
+    if (n + 1 < 32) eval = epi_form(n + 1);
+  };
+  auto epi_value = [&](Tile T, bool partial, int n) {       // whole value n, optionally bounds-checked
+    if (!partial) {
+      epi_store(n);
+      epi_accum(n);
+    } else {
+      WS_IDS;
+      const int m = n >> 4, i = n & 15;
+      const int ro = m * 32 + (i & 3) + 8 * (i >> 2);
+      const float val = epi_form(n);
+      if (T.tile * WS_TM + ro + 4 * (lane >> 5) < a.Lout) {
+        *reinterpret_cast<float*>(ybase_e + ro * (WS_C * 4) + y_off) = val;
+        ssum += val; ssq = fmaf(val, val, ssq);
+      }
+    }
+  };
+  // statistics of a tile: fold the two lane halves (a lane owns one column, the other half holds the
+  // rows +4) and store; both halves then hold the same sums and write the same slab entry
+  float st_s = 0.0f, st_q = 0.0f;
+  char* stbase_e = nullptr;                                 // statistics slab of the epilogue tile
+  auto epi_stats = [&](Tile T, int part = 2) {              // 0: fold the lane halves, 1: store, 2: both
+    if (has_stats) {
+      if (part != 1) {
+        st_s = ssum + __int_as_float(__builtin_amdgcn_ds_bpermute((int)swap_off, __float_as_int(ssum)));
+        st_q = ssq + __int_as_float(__builtin_amdgcn_ds_bpermute((int)swap_off, __float_as_int(ssq)));
+      }
+      if (part != 0) ws_store_b64(stbase_e, st_off, make_uint2(__float_as_uint(st_s), __float_as_uint(st_q)));
+    }
+    if (part != 0) { ssum = 0.0f; ssq = 0.0f; }
+  };
+
+  int toff[WS_NTAPS];
+#pragma unroll
+  for (int t = 0; t < WS_NTAPS; ++t) toff[t] = (a.taps.off[0][t] - a.rowmin) * WS_PITCH;
+
+  // ================= prologue: first tile staged without overlap =================
+  // Past the end of the range the "next" tiles are clamped to its last one: the transform / DMA
+  // slots then repeat that tile's work (same values to the same places) instead of branching.
+  Tile Tc = tile_of(first), Tn = tile_of(first + 1 < last ? first + 1 : last - 1), Tp = Tc;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) csum[q] = 0.0f;
+  {
+    const bool ec = is_edge(Tc), en = is_edge(Tn);
+    xbase_d = row_block(a.x, Tc.b, a.Lin, Tc.tile * WS_TM + a.rowmin, WS_C * 4);
+    if constexpr (PRO2) x2base_d = row_block(a.nb_x, Tc.b, a.Lin, Tc.tile * WS_TM + a.rowmin, WS_C * 4);
+    aobase_t = const_cast<char*>(row_block(a.a_out, Tc.b, a.Lin, Tc.tile * WS_TM + a.rowmin, WS_C * 2));
+    pl_cur = pl_off;
+#pragma unroll
+    for (int j = 0; j < WS_DPW; ++j) dma_piece(Tc, ec, j);
+    xbase_d = row_block(a.x, Tn.b, a.Lin, Tn.tile * WS_TM + a.rowmin, WS_C * 4);
+    if constexpr (PRO2) x2base_d = row_block(a.nb_x, Tn.b, a.Lin, Tn.tile * WS_TM + a.rowmin, WS_C * 4);
+    if (MODE != 0) load_consts(Tc.b);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+    for (int j = 0; j < WS_DPW; ++j) {
+      piece_read(j);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) piece_elem(Tc, ec, j, q);
+      piece_write(j);
+      piece_cache(Tc, ec, j);
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the raw piece is in registers before its refill
+      dma_piece(Tn, en, j);
+    }
   }
+  colsum_put(0);
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  colsum_out(first, 0);
+
+  // ================= the tile walk =================
+  // iteration (t, it): MFMA loop of tile t from planes[it & 1]; in its filler slots the epilogue of
+  // tile t-1 (from the copied accumulators), the transform of tile t+1 into planes[(it+1) & 1] and
+  // the refill DMA of tile t+2.  One barrier per tile.
+  for (int t = first, it = 0; t < last; ++t, ++it) {
+    const bool doE = t > first, doT = t + 1 < last;
+    const Tile Tnn = t + 2 < last ? next_tile(Tn) : Tn;       // (clamped: Tn is already the last tile then)
+    const bool edgeT = is_edge(Tn), edgeD = is_edge(Tnn);
+    const bool partialE = Tp.tile * WS_TM + WS_TM > a.Lout;
+    // the slots hold the interior forms only; a tile at the end of an utterance (2 of 315 at the
+    // training length) gets its masked transform / clamped DMA after the loop, a partial output tile
+    // its bounds-checked epilogue in front of it, not overlapped
+    const bool slotE = doE && !partialE, slotT = !edgeT, slotD = !edgeT && !edgeD;
+    if (MODE != 0 && Tn.b != cur_b) load_consts(Tn.b);
+    xbase_d = row_block(a.x, Tnn.b, a.Lin, Tnn.tile * WS_TM + a.rowmin, WS_C * 4);
+    if constexpr (PRO2) x2base_d = row_block(a.nb_x, Tnn.b, a.Lin, Tnn.tile * WS_TM + a.rowmin, WS_C * 4);
+    aobase_t = const_cast<char*>(row_block(a.a_out, Tn.b, a.Lin, Tn.tile * WS_TM + a.rowmin, WS_C * 2));
+    ybase_e = const_cast<char*>(row_block(a.y, Tp.b, a.Lout, Tp.tile * WS_TM, WS_C * 4));
+    stbase_e = const_cast<char*>(row_block(a.stats, Tp.b, a.ntiles, Tp.tile, WS_C * 8));
+    pl_cur = (it + 1) & 1 ? pl_off + WS_BUF_BYTES : pl_off;
+    asm volatile("" : "+v"(pl_cur));
+    if (doE && partialE) {
+#pragma unroll
+      for (int n = 0; n < 32; ++n) epi_value(Tp, true, n);
+      epi_stats(Tp);
+    }
+    WS_STAMP(it, 0);
+    int lanem = lane_;
+    asm volatile("" : "+v"(lanem));
+    const bf16_t* ab = planes + (size_t)(it & 1) * 2 * WS_PLANE + (lanem & 31) * WS_PITCH + (lanem >> 5) * 8;
+    // A fragments of the next step, read behind MFMAs 0 and 1 of this one, i.e. four MFMAs or more
+    // ahead of their use (hipcc waits for all of them once, in front of the next step's MFMA 0): the
+    // lo halves (MFMAs 0, 1) have one slot, refilled behind their last use, the hi halves (2..5) two
+    bf16x8 ah[2][2], al[2];
+    auto a_ptr = [&](int s, int m) {
+      const int tp = s / WS_KSTEPS, k = s % WS_KSTEPS;
+      return ab + toff[tp] + m * 32 * WS_PITCH + k * 16;
+    };
+    auto load_ah = [&](int s, int m) { ah[s & 1][m] = *reinterpret_cast<const bf16x8*>(a_ptr(s, m)); };
+    auto load_al = [&](int s, int m) { al[m] = *reinterpret_cast<const bf16x8*>(a_ptr(s, m) + WS_PLANE); };
+    // One tile: 240 single-MFMA asm statements with filler slot f behind statement f.  FAST: the
+    // steady state (a full previous tile to store, interior tiles to transform and to fetch) with
+    // every slot filled, unconditionally; otherwise the bare MFMA loop, the other work around it.
+    auto tile_body = [&](auto fast_c) {
+      constexpr bool FAST = decltype(fast_c)::value;
+      auto filler = [&](auto f_c) {
+        constexpr int fs = decltype(f_c)::value;
+        if constexpr ((SA_ABL & 8) != 0 || !FAST) return;
+        if constexpr (fs < 64) {
+          if constexpr (fs % 2 == 0) epi_store(fs / 2); else epi_accum(fs / 2);
+        } else if constexpr (fs == 64 || fs == 65) {
+          epi_stats(Tp, fs - 64);
+        } else if constexpr (fs == 66) {
+          WS_STAMP(it, 3);
+        } else if constexpr (fs == WS_FT - 1) {
+          WS_STAMP(it, 4);
+          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+          WS_STAMP(it, 5);
+          piece_read(0);
+        } else if constexpr (fs >= WS_FT) {
+          constexpr int j = (fs - WS_FT) / 14, k = (fs - WS_FT) % 14, h = k & 1;
+          if constexpr (k < 8) piece_stage(Tn, j, k / 2, h);
+          if constexpr (j + 1 < WS_DPW && k == 1) piece_read(j + 1, 0);    // stage 0 has consumed the raw piece
+          if constexpr (j + 1 < WS_DPW && k == 3 && PRO2) piece_read(j + 1, 1);
+          if constexpr (k == 8 || k == 9) piece_write(j, h);
+          if constexpr (k == 10) piece_cache(Tn, false, j);
+          if constexpr (k == 12 || (k == 13 && PRO2)) dma_piece(Tnn, false, j, h);
+        }
+      };
+      load_al(0, 0); load_al(0, 1); load_ah(0, 0); load_ah(0, 1);
+      // The MFMAs are inline asm so that the weight fragments are AGPR operands where they live
+      // (left to itself hipcc parks them in AGPRs and copies each one to VGPRs in front of every
+      // use).  The first WS_NAGPR_FRAGS (tap, k-step) pairs take 240 of the 256 AGPRs, the rest stay
+      // in VGPRs.  Hazards (cdna_hip_programming.md 5.7 item 2): an accumulate chain needs no wait
+      // states; the A fragments come from ds_read (waited for by hipcc, which sees the operand); the
+      // accumulators are read by VALU code only after the s_nop block below (tools/ws_audit.py
+      // checks the ISA).
+      ws_static_for<0, WS_NTAPS * WS_KSTEPS>([&](auto s_c) {
+        constexpr int s = decltype(s_c)::value;
+        constexpr int tp = s / WS_KSTEPS, k = s % WS_KSTEPS, sl = s & 1;
+        constexpr bool more = s + 1 < WS_NTAPS * WS_KSTEPS;
+        __builtin_amdgcn_sched_barrier(0);
+#define WS_MFMA1(M, A, BC, B) \
+        asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(acc[M]) : "v"(A), BC(B))
+#define WS_AL(M) if constexpr (more) { __builtin_amdgcn_sched_barrier(0); load_al(s + 1, M); load_ah(s + 1, M); }
+#define WS_AH(M)
+#define WS_SLOT(I) __builtin_amdgcn_sched_barrier(0); filler(std::integral_constant<int, 6 * s + (I)>{}); __builtin_amdgcn_sched_barrier(0)
+        if constexpr ((SA_ABL & 1) != 0) {
+          asm volatile("" :: "v"(ah[sl][0]), "v"(al[0]), "v"(ah[sl][1]), "v"(al[1]));
+          WS_AL(0); WS_AL(1); WS_AH(0); WS_AH(1);
+          WS_SLOT(0); WS_SLOT(1); WS_SLOT(2); WS_SLOT(3); WS_SLOT(4); WS_SLOT(5);
+        } else {
+          if constexpr (s == 0) {
+            asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, 0" : "=&v"(acc[0]) : "v"(al[0]), "a"(Bh[0][0]));
+            WS_AL(0); WS_SLOT(0);
+            asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, 0" : "=&v"(acc[1]) : "v"(al[1]), "a"(Bh[0][0]));
+            WS_AL(1); WS_SLOT(1);
+          } else if constexpr (s < WS_NAGPR_FRAGS) {
+            WS_MFMA1(0, al[0], "a", Bh[tp][k]); WS_AL(0); WS_SLOT(0);
+            WS_MFMA1(1, al[1], "a", Bh[tp][k]); WS_AL(1); WS_SLOT(1);
+          } else {
+            WS_MFMA1(0, al[0], "v", Bh[tp][k]); WS_AL(0); WS_SLOT(0);
+            WS_MFMA1(1, al[1], "v", Bh[tp][k]); WS_AL(1); WS_SLOT(1);
+          }
+          if constexpr (s < WS_NAGPR_FRAGS) {
+            WS_MFMA1(0, ah[sl][0], "a", Bl[tp][k]); WS_AH(0); WS_SLOT(2);
+            WS_MFMA1(1, ah[sl][1], "a", Bl[tp][k]); WS_AH(1); WS_SLOT(3);
+            WS_MFMA1(0, ah[sl][0], "a", Bh[tp][k]); WS_SLOT(4);
+            WS_MFMA1(1, ah[sl][1], "a", Bh[tp][k]); WS_SLOT(5);
+          } else {
+            WS_MFMA1(0, ah[sl][0], "v", Bl[tp][k]); WS_AH(0); WS_SLOT(2);
+            WS_MFMA1(1, ah[sl][1], "v", Bl[tp][k]); WS_AH(1); WS_SLOT(3);
+            WS_MFMA1(0, ah[sl][0], "v", Bh[tp][k]); WS_SLOT(4);
+            WS_MFMA1(1, ah[sl][1], "v", Bh[tp][k]); WS_SLOT(5);
+          }
+        }
+#undef WS_MFMA1
+#undef WS_SLOT
+#undef WS_AL
+#undef WS_AH
+      });
+    };
+#ifdef SA_WS_NOFAST                                        // diagnostic build: every tile through the un-overlapped path
+    const bool fast = false;
+#else
+    const bool fast = slotE && slotT && slotD;
+#endif
+    if (fast) {
+      tile_body(std::true_type{});
+    } else {
+      if (doE && !partialE) {                              // (a partial tile had its epilogue above)
+#pragma unroll
+        for (int n = 0; n < 32; ++n) epi_value(Tp, false, n);
+        epi_stats(Tp);
+      }
+      tile_body(std::false_type{});
+    }
+    WS_STAMP(it, 1);
+    if (!fast) {                                           // transform of the next tile (masked if it is at the end of an
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // utterance) and the DMA of the one after, not overlapped
+#pragma unroll
+      for (int j = 0; j < WS_DPW; ++j) {
+        piece_read(j);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) piece_elem(Tn, edgeT, j, q);
+        piece_write(j);
+        piece_cache(Tn, edgeT, j);
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the raw pieces are in registers before their refill
+#pragma unroll
+      for (int j = 0; j < WS_DPW; ++j) dma_piece(Tnn, edgeD, j);
+    }
+    colsum_put(it + 1);
+    // MFMA result -> VALU reader wait states (two back-to-back 8-pass MFMAs have just been issued:
+    // 2 x 32 cycles + write-back), then the accumulators move to their epilogue copy.  The copy is
+    // asm on purpose: given a plain assignment hipcc coalesces it away by MIGRATING the live
+    // accumulators to the copy's registers in the middle of the MFMA loop (v_mov_b64 right behind an
+    // asm MFMA whose latency it does not know: stale values in the first registers).
+    asm volatile("s_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15" : "+v"(acc[0]), "+v"(acc[1]));
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        float v;
+        asm volatile("v_mov_b32 %0, %1" : "=v"(v) : "v"(acc[m][i]));
+        accp[m][i] = v;
+      }
+    eval = epi_form(0);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();                          // planes[(it+1) & 1] complete; planes[it & 1] free
+    WS_STAMP(it, 2);
+    if (doT) colsum_out(t + 1, it + 1);
+    Tp = Tc; Tc = Tn; Tn = Tnn;
+  }
+  // ================= tail: epilogue of the last tile =================
+  {
+    const bool partialE = Tp.tile * WS_TM + WS_TM > a.Lout;
+    ybase_e = const_cast<char*>(row_block(a.y, Tp.b, a.Lout, Tp.tile * WS_TM, WS_C * 4));
+    stbase_e = const_cast<char*>(row_block(a.stats, Tp.b, a.ntiles, Tp.tile, WS_C * 8));
+    if (!partialE) eval = epi_form(0);
+#pragma unroll
+    for (int n = 0; n < 32; ++n) epi_value(Tp, partialE, n);
+    epi_stats(Tp);
+  }
+#undef WS_IDS
 }
 
 template <int MODE>
@@ -383,6 +702,7 @@ int launch_ws(const SaConvArgs& a, hipStream_t st) {
   if ((a.a_out || a.nb_colsum) &&
       (omin > 0 || omax < 0 || (args.ntiles - 1) * WS_TM + omin + WS_ROWS < a.Lin))
     return -22;                                           // every input row must be staged by the tile that owns it
+  if ((long)a.B * a.Lin >= (1L << 31) - 64 || (long)a.B * a.Lout >= (1L << 31) - 64) return -22;   // 32-bit row indices in the kernel
   const size_t lds = 2 * WS_BUF_BYTES + (MODE == 2 ? 2 : 1) * WS_RAW_BYTES + (MODE == 2 ? 2 * 4 * WS_C * 4 : 0);
   auto kern = sa_conv_ws_kernel<MODE>;
   static bool attr_set = false;
@@ -413,13 +733,19 @@ bool sa_conv_ws_covers(int dtype, int cin, int cout, int sa, int u, const SaConv
   if (a->taps.ntaps[0] != WS_NTAPS || a->pro_stats || a->s2 || a->t2 || a->wscale) return false;
   if (a->ep_mode) return false;
   if (a->tile_rows && a->tile_rows != WS_TM) return false;
+#ifndef SA_WS_PRO2
+  if (a->nb_x) return false;                              // data gradients stay on the one-tile kernel (header)
+#else
   if (a->nb_x) return !a->s1 && !a->swish && a->nb_c1 && a->nb_c2 && a->nb_c3;
+#endif
   if (a->s1) return a->t1 && a->swish;                    // affine + x*sigmoid(x)
   return !a->swish;
 }
 
 int sa_conv_ws_dispatch(const SaConvArgs* a, hipStream_t st) {
+#ifdef SA_WS_PRO2                                         // experiment build: MODE 2 without a fused epilogue
   if (a->nb_x) return launch_ws<2>(*a, st);
+#endif
   if (a->s1) return launch_ws<1>(*a, st);
   return launch_ws<0>(*a, st);
 }

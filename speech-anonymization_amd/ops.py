@@ -160,13 +160,13 @@ def _conv_geometry(code, cin, cout, u, Lout):
     return nt.value, ns.value
 
 
-def conv_impl(pingpong=False, tile_rows=0, pp_rows=0, ws=False):
-    """kernel choice for the f32 / bf16x3 policies (A/B timing, kernel tests): the
-    one-tile-per-workgroup kernel, the two-groups-in-anti-phase kernel (sa_conv_pp.hip) or the
-    weight-stationary kernel for the 128->128 layers (sa_conv_ws.hip; the other shapes stay on the
-    one-tile kernel); tile-row knobs of the first two (0 = policy)."""
+def conv_impl(pingpong=False, tile_rows=0, pp_rows=0, ws=True):
+    """kernel choice for the f32 / bf16x3 policies (A/B timing, kernel tests).  Default: the
+    weight-stationary kernel (sa_conv_ws.hip) for the large 128->128 bf16x3 launches it covers, the
+    one-tile-per-workgroup kernel for everything else; ws=False: one-tile kernel only; pingpong=True:
+    the two-groups-in-anti-phase kernel (sa_conv_pp.hip).  Tile-row knobs of the latter two (0 = policy)."""
     lib = L.load()
-    L.check(lib.sa_conv_gemm_set_impl(2 if ws else int(bool(pingpong))), "sa_conv_gemm_set_impl")
+    L.check(lib.sa_conv_gemm_set_impl(1 if pingpong else (2 if ws else 0)), "sa_conv_gemm_set_impl")
     L.check(lib.sa_conv_gemm_set_tile_rows(int(tile_rows)), "sa_conv_gemm_set_tile_rows")
     L.check(lib.sa_conv_pp_set_tile_rows(int(pp_rows)), "sa_conv_pp_set_tile_rows")
     _conv_geometry.cache_clear()

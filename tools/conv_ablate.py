@@ -23,6 +23,8 @@ def one():
         impl = os.environ["SA_CONV_IMPL"]
         ops.conv_impl(pingpong=impl.startswith("pp"), pp_rows=64 if impl == "pp64" else 0,
                       tile_rows=128 if impl == "old128" else 0, ws=impl == "ws")
+    else:
+        ops.conv_impl(ws=False)
     B, L4 = int(os.environ.get("KB_B", "32")), 20160
     code = L.BF16X3
     g = torch.Generator(device="cpu").manual_seed(1)

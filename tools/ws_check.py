@@ -1,6 +1,6 @@
 """Weight-stationary conv kernel against the one-tile kernel on the same inputs (bit-equal outputs
-expected: same operand split, same accumulation order), forward-type launches and the
-normalisation-backward prologue.  python tools/ws_check.py [B] [L]"""
+expected: same operand split, same accumulation order).  "nb" / "dgrad" run on the one-tile kernel in
+both arms unless the library was built with -DSA_WS_PRO2.  python tools/ws_check.py [B] [L]"""
 import os, sys
 R = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, R)
@@ -45,7 +45,7 @@ def run(kind):
 
 ok = True
 for kind in ("plain", "fwd", "nb", "dgrad"):
-    ops.conv_impl()
+    ops.conv_impl(ws=False)
     ref = run(kind)
     ops.conv_impl(ws=True)
     got = run(kind)
@@ -58,5 +58,12 @@ for kind in ("plain", "fwd", "nb", "dgrad"):
         print(f"{kind:6s} out{i} shape {tuple(r.shape)} max|d| {d:.3e} rel {rel:.2e} {'bit-equal' if exact else ''}", flush=True)
         if rel > 1e-5:
             ok = False
+        if not exact and r.dim() == 3 and r.shape[1] == Ln and os.environ.get("WS_WHERE"):
+            if True:
+                bad = ((r - o).abs() > 0).nonzero()
+                rows = sorted(set((int(b_), int(l_)) for b_, l_, _ in bad.tolist()))
+                cols = sorted(set(int(c_) for _, _, c_ in bad.tolist()))
+                print("   bad rows (b, l):", rows[:40], "... total", len(rows))
+                print("   bad cols:", cols[:40], "... total", len(cols))
 print("OK" if ok else "MISMATCH")
 sys.exit(0 if ok else 1)

@@ -60,11 +60,11 @@ buf = (C.c_ulonglong * (64 * 8))()
 lib.sa_ws_dbg_read(buf)
 a = np.array(list(buf), dtype=np.float64).reshape(64, 8)
 n = int((a[:, 0] > 0).sum())
-span = a[n - 1, 3] - a[0, 0]
+span = a[n - 1, 0] - a[0, 0]
 print(f"ABL={abl} {which}: {us:.1f} us per launch; workgroup 7: {n - 1} tiles in {span:.0f} ticks "
       f"=> {span / (n - 1):.0f} ticks per tile, {us * 1e3 / span:.3f} ns per tick if the workgroup spans the launch")
-print("per tile (ticks): wait DMA | transform | dma issue + epilogue(prev) | barrier wait | MFMA loop | total")
-for it in range(min(n, int(os.environ.get("WS_ROWS", "12")))):
+print("per tile (ticks): slots 0..32 (epilogue) | slots 33..55 (MFMA only) | vmcnt(0) wait | slots 56..119 (transform + DMA) | nops, copy, barrier | total")
+for it in range(min(n - 1, int(os.environ.get("WS_ROWS", "12")))):
     r = a[it]
-    nxt = a[it + 1, 0] if it + 1 < n and a[it + 1, 0] else r[5]
-    print(f"it={it:2d}  {r[1]-r[0]:7.0f} {r[2]-r[1]:7.0f} {r[3]-r[2]:7.0f} {r[4]-r[3]:7.0f} {r[5]-r[4]:7.0f}   {nxt-r[0]:7.0f}")
+    nxt = a[it + 1, 0]
+    print(f"it={it:2d}  {r[3]-r[0]:7.0f} {r[4]-r[3]:7.0f} {r[5]-r[4]:7.0f} {r[1]-r[5]:7.0f} {nxt-r[1]:7.0f}   {nxt-r[0]:7.0f}")
