@@ -113,6 +113,9 @@ int sa_conv_gemm_geometry(int dtype, int cin, int cout, int u, int Lout, int* nt
  * inputs, the same output bits.  0: one-tile kernel only.  1: the ping-pong kernel (sa_conv_pp.hip)
  * for the f32 / bf16x3 policies (opt-in, A/B timing).  sa_conv_pp_set_tile_rows: 0 (policy), 64, 128. */
 int sa_conv_gemm_set_impl(int impl);
+/* which kernel serves this launch under the current choice: 0 one-tile, 1 ping-pong, 2 weight-stationary
+ * (profiling tools name the kernel they time with it) */
+int sa_conv_gemm_route(int dtype, int cin, int cout, int sa, int u, const SaConvArgs* a);
 int sa_conv_pp_set_tile_rows(int rows);
 
 /* fp32 master weights -> fragment-major MFMA operand image (K = GEMM reduction channels,

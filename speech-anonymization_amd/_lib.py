@@ -78,7 +78,7 @@ FIN_IN_FWD, FIN_IN_BWD, FIN_BN_FWD, FIN_BN_BWD, FIN_BIAS = 1, 2, 3, 4, 5
 # every symbol include/sa_hip.h declares (checked by tests/test_abi.py on CPU)
 SYMBOLS = [
     "sa_conv_gemm", "sa_abi_sizeof", "sa_conv_gemm_ntiles", "sa_conv_gemm_ntiles_tm", "sa_conv_gemm_set_tile_rows",
-    "sa_conv_gemm_geometry", "sa_conv_gemm_set_impl", "sa_conv_pp_set_tile_rows", "sa_pack_weights", "sa_pack_weights_multi", "sa_pack_scales_multi", "sa_wgrad", "sa_wgrad_kw", "sa_wgrad_reduce",
+    "sa_conv_gemm_geometry", "sa_conv_gemm_set_impl", "sa_conv_gemm_route", "sa_conv_pp_set_tile_rows", "sa_pack_weights", "sa_pack_weights_multi", "sa_pack_scales_multi", "sa_wgrad", "sa_wgrad_kw", "sa_wgrad_reduce",
     "sa_conv1toC", "sa_conv1toC_ntiles", "sa_convCto1", "sa_wgrad1C", "sa_wgrad1C_nchunk",
     "sa_sum_slabs", "sa_ew_stats", "sa_ew_apply", "sa_ew_ntiles", "sa_act_stats",
     "sa_sum_partials", "sa_sum_rows_d", "sa_reduce_finalize", "sa_fin_in_fwd", "sa_fin_bn_fwd", "sa_fin_bn_eval", "sa_fin_norm_bwd", "sa_fin_bias",

@@ -628,16 +628,28 @@ extern "C" int sa_abi_sizeof(int which) {
   }
 }
 
+// which kernel sa_conv_gemm routes this launch to: 0 one-tile, 1 ping-pong, 2 weight-stationary
+static int conv_route(int dtype, int cin, int cout, int sa, int u, const SaConvArgs* a) {
+  if (uses_pp(dtype)) return 1;
+  if (g_use_ws && tile_rows(cin, cout, u) == 64 && sa_conv_ws_covers(dtype, cin, cout, sa, u, a) &&
+      (long)a->B * sa_div_up(a->Lout, 64) >= 512)
+    return 2;
+  return 0;
+}
+extern "C" int sa_conv_gemm_route(int dtype, int cin, int cout, int sa, int u, const SaConvArgs* a) {
+  if (!a || a->B <= 0 || a->Lout <= 0) return -22;
+  return conv_route(dtype, cin, cout, sa, u, a);
+}
+
 // C-ABI entry (see include/sa_hip.h).  Returns 0, or a negative hipError_t / errno.
 extern "C" int sa_conv_gemm(int dtype, int cin, int cout, int sa, int u, const SaConvArgs* a,
                             void* stream) {
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   if (!a || !a->x || !a->wp || !a->y || a->B <= 0 || a->Lin <= 0 || a->Lout <= 0) return -22;
   if (a->ep_mode < 0 || a->ep_mode > 2 || (a->ep_mode && !a->ep_x)) return -22;
-  if (uses_pp(dtype)) return sa_conv_pp_dispatch(dtype, cin, cout, sa, u, a, st);
-  if (g_use_ws && tile_rows(cin, cout, u) == 64 && sa_conv_ws_covers(dtype, cin, cout, sa, u, a) &&
-      (long)a->B * sa_div_up(a->Lout, 64) >= 512)
-    return sa_conv_ws_dispatch(a, st);
+  const int route = conv_route(dtype, cin, cout, sa, u, a);
+  if (route == 1) return sa_conv_pp_dispatch(dtype, cin, cout, sa, u, a, st);
+  if (route == 2) return sa_conv_ws_dispatch(a, st);
   SA_CONV_CASE(32, 64, 2, 1)
   SA_CONV_CASE(64, 64, 1, 1)
   SA_CONV_CASE(64, 128, 2, 1)

@@ -732,6 +732,15 @@ bool sa_conv_ws_covers(int dtype, int cin, int cout, int sa, int u, const SaConv
   if (dtype != SA_BF16X3 || cin != WS_C || cout != WS_C || sa != 1 || u != 1) return false;
   if (a->taps.ntaps[0] != WS_NTAPS || a->pro_stats || a->s2 || a->t2 || a->wscale) return false;
   if (a->ep_mode) return false;
+  int omin = 1 << 30, omax = -(1 << 30);
+  for (int t = 0; t < WS_NTAPS; ++t) {
+    omin = a->taps.off[0][t] < omin ? a->taps.off[0][t] : omin;
+    omax = a->taps.off[0][t] > omax ? a->taps.off[0][t] : omax;
+  }
+  if (omax - omin != WS_HALO) return false;               // 5 taps at unit spacing
+  // the slots' ownership test (operand cache, column sums) is written for the 'same'-padding
+  // geometry: two halo rows on either side = the first and the last DMA piece of a tile
+  if ((a->a_out || a->nb_colsum) && omin != -2) return false;
   if (a->tile_rows && a->tile_rows != WS_TM) return false;
 #ifndef SA_WS_PRO2
   if (a->nb_x) return false;                              // data gradients stay on the one-tile kernel (header)

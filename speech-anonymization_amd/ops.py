@@ -40,10 +40,10 @@ class _Profile:
     recorded on the stream the kernel is launched on = torch's current stream)."""
 
     def __init__(self):
-        self.key, self.ev, self.bytes, self.alg_bytes, self.flops = None, [], 0, 0, 0
+        self.key, self.kinds = None, {}
 
     def enable(self, key):
-        self.key, self.ev, self.bytes, self.alg_bytes, self.flops = key, [], 0, 0, 0
+        self.key, self.kinds = key, {}
 
     def start(self, key):
         if key != self.key:
@@ -52,22 +52,28 @@ class _Profile:
         e.record()
         return e
 
-    def stop(self, e0, nbytes, flops, alg_bytes=None):
+    def stop(self, e0, nbytes, flops, alg_bytes=None, kind=""):
         """nbytes: what the launch is designed to move; alg_bytes: SURVEY 8(d)'s algorithmic
-        figure (inputs + outputs once, + the stored tensor a fused backward epilogue re-reads)."""
+        figure (inputs + outputs once, + the stored tensor a fused backward epilogue re-reads);
+        kind: which device kernel served the launch (one family can be served by several)."""
         e1 = torch.cuda.Event(enable_timing=True)
         e1.record()
-        self.ev.append((e0, e1))
-        self.bytes += nbytes
-        self.alg_bytes += nbytes if alg_bytes is None else alg_bytes
-        self.flops += flops
+        k = self.kinds.setdefault(kind, {"ev": [], "bytes": 0, "alg_bytes": 0, "flops": 0})
+        k["ev"].append((e0, e1))
+        k["bytes"] += nbytes
+        k["alg_bytes"] += nbytes if alg_bytes is None else alg_bytes
+        k["flops"] += flops
 
     def collect(self):
+        """one record per device kernel of the family, largest total time first"""
         torch.cuda.synchronize()
-        ms = sum(a.elapsed_time(b) for a, b in self.ev)
-        out = {"kernel": self.key, "launches": len(self.ev), "ms": ms, "bytes": self.bytes,
-               "alg_bytes": self.alg_bytes, "flops": self.flops}
-        self.key, self.ev = None, []
+        out = []
+        for kind, k in self.kinds.items():
+            out.append({"kernel": kind or self.key, "family": self.key, "launches": len(k["ev"]),
+                        "ms": sum(a.elapsed_time(b) for a, b in k["ev"]), "bytes": k["bytes"],
+                        "alg_bytes": k["alg_bytes"], "flops": k["flops"]})
+        out.sort(key=lambda r: -r["ms"])
+        self.key, self.kinds = None, {}
         return out
 
 
@@ -232,9 +238,14 @@ def conv_gemm(x, wp, bias, cin, cout, sa, u, phases, Lout, s1=None, t1=None, s2=
         if nb:
             extra += x.numel() * esz                                             # stored forward tensor of the layer above
         io = (x.numel() + y.numel()) * esz
+        route = lib.sa_conv_gemm_route(kc, cin, cout, sa, u, C.byref(a))
+        tname = {L.F32: "float", L.BF16: "bf16_t", L.BF16X3: "bf16x3_t", L.BF16X1F: "bf16x1f_t", L.FP8: "fp8_t"}[kc]
+        kind = (f"sa_conv_ws_kernel<{1 if s1 is not None else 0}> ({tname}, {cin}->{cout})" if route == 2 else
+                f"sa_conv_pp_kernel<{tname},{cin},{cout},{sa},{u}>" if route == 1 else
+                f"sa_conv_gemm_kernel<{tname},{cin},{cout},{sa},{u}{',nb prologue' if nb else ''}>")
         PROFILE.stop(e0, io + ntap * cin * cout * esz + extra,
                      2 * B * (-(-Lout // u)) * ntap * cin * cout,
-                     alg_bytes=io + (y.numel() * esz if ep else 0))
+                     alg_bytes=io + (y.numel() * esz if ep else 0), kind=kind)
     out_t = (y, stats) if want_stats else (y,)
     if nb and nb.get("want_colsum"):
         out_t = out_t + (colsum,)

@@ -658,6 +658,85 @@ def test_pingpong_conv_kernel_in_the_model():
             assert rel_mse(out[1][2][k], g) < 1e-5, k       # classifier branch amplifies the slab-order noise
 
 
+@pytest.mark.parametrize("Ln,pad", [(20160, 2), (20001, 2), (20164, 0)], ids=["train", "ragged", "valid"])
+@pytest.mark.parametrize("mode", ["plain", "swish_stats_cache", "relu_stats"])
+def test_weight_stationary_conv_kernel(mode, Ln, pad):
+    """sa_conv_ws.hip (persistent, weights in registers, rows by LDS-DMA, epilogue / transform in the
+    MFMA loop's issue gaps) serves the large 128->128 bf16x3 forward launches: same output BITS as the
+    one-tile kernel (same operand split, same accumulation order), statistics equal up to the order
+    of the in-tile sums, and both against the fp32 torch convolution.  `ragged`: a partial last tile;
+    `valid`: no padding, Lout = Lin - 4 (the trailing input rows belong to the last tile)."""
+    from speech_anonymization_amd import _lib as L, ops
+    d, B = dev(), 4
+    g = torch.Generator().manual_seed(11)
+    x = torch.randn(B, Ln, 128, generator=g).to(d)
+    w = (torch.randn(128, 128, 5, generator=g) * 0.05).to(d)
+    bias = torch.randn(128, generator=g).to(d)
+    s1 = (torch.rand(B, 128, generator=g) + 0.5).to(d)
+    t1 = (torch.randn(B, 128, generator=g) * 0.1).to(d)
+    wp = ops.pack_weights(w, "conv_fwd", torch.float32, L.BF16X3)
+    Lout = Ln + 2 * pad - 4
+    kw = dict(code=L.BF16X3)
+    if mode == "swish_stats_cache":
+        kw.update(s1=s1, t1=t1, swish=True, want_stats=True)
+    elif mode == "relu_stats":
+        kw.update(relu=True, want_stats=True)
+
+    def run(ws):
+        ops.conv_impl(ws=ws)
+        a_out = torch.full((B, Ln, 128), float("nan"), dtype=torch.bfloat16, device=d) if mode == "swish_stats_cache" else None
+        a = L.SaConvArgs()
+        r = ops.conv_gemm(x, wp, bias if mode != "plain" else None, 128, 128, 1, 1, ops.taps_conv(5, 1, pad), Lout,
+                          a_out=a_out, **kw)
+        torch.cuda.synchronize()
+        return (r if isinstance(r, tuple) else (r,)) + ((a_out,) if a_out is not None else ())
+
+    try:
+        ref, got = run(False), run(True)
+    finally:
+        ops.conv_impl()
+    assert torch.equal(ref[0], got[0])                               # y: bit-equal
+    if mode != "plain":
+        assert ref[1].shape == got[1].shape and torch.allclose(ref[1], got[1], rtol=2e-6, atol=1e-3)
+    if mode == "swish_stats_cache":
+        assert not torch.isnan(got[2].float()).any() and torch.equal(ref[2], got[2])
+    xin = torch.nn.functional.silu(x * s1[:, None, :] + t1[:, None, :]) if mode == "swish_stats_cache" else x
+    yref = F.conv1d(xin.permute(0, 2, 1), w, bias if mode != "plain" else None, padding=pad).permute(0, 2, 1)
+    if mode == "relu_stats":
+        yref = yref.relu()
+    assert rel_mse(got[0], yref) < 2e-9
+
+
+def test_weight_stationary_conv_routing():
+    """what goes to the weight-stationary kernel: bf16x3 128->128 stride-1 5-tap launches with at
+    least 512 tiles and no pro_stats / second affine / fused backward epilogue / normalisation-
+    backward prologue; everything else to the one-tile kernel"""
+    import ctypes as C
+    from speech_anonymization_amd import _lib as L, ops
+    lib = L.load()
+    ops.conv_impl()
+    a = L.SaConvArgs()
+    a.B, a.Lin, a.Lout = 32, 20160, 20160
+    a.taps = L.make_taps(ops.taps_conv(5, 1, 2))
+    route = lambda code=L.BF16X3, cin=128, cout=128: lib.sa_conv_gemm_route(code, cin, cout, 1, 1, C.byref(a))
+    assert route() == 2
+    assert route(L.F32) == 0 and route(L.BF16X3, 64, 64) == 0
+    a.B = 1
+    assert route() == 0                                              # 315 tiles: too few to fill the chip twice
+    a.B = 32
+    a.ep_mode = 1
+    assert route() == 0
+    a.ep_mode = 0
+    a.taps = L.make_taps(ops.taps_conv(3, 2, 2))
+    assert route() == 0
+    ops.conv_impl(ws=False)
+    a.taps = L.make_taps(ops.taps_conv(5, 1, 2))
+    try:
+        assert route() == 0
+    finally:
+        ops.conv_impl()
+
+
 def _fp8_e4m3(t):
     """OCP e4m3 round trip (saturating), the quantisation of the SA_FP8 operand path"""
     return t.clamp(-448.0, 448.0).to(torch.float8_e4m3fn).float()
