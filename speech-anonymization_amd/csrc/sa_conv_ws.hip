@@ -23,8 +23,8 @@
 //   per tile g, per wave:   wait DMA(g) | transform(g) -> planes[g&1] | issue DMA(g+1) |
 //                           epilogue(g-1) from registers | barrier | MFMA(g)
 //
-// Launches it does not cover stay on sa_conv_gemm.hip: pro_stats, the generic two-affine prologue,
-// and the data gradients.  A fused data gradient reads two more fp32 tiles per output tile (the stored
+// Launches it does not cover stay on sa_conv_gemm.hip: 3-tap / dilated taps (the other two TDNN
+// layers) and the data gradients.  A fused data gradient reads two more fp32 tiles per output tile (the stored
 // forward tensor for the normalisation-backward prologue, and it again + a second gradient in the
 // backward epilogue): 70 KB more LDS or 64 more registers per lane than this structure has left
 // (512 registers: 320 weights, 64 accumulators + their epilogue copy, 24 A fragments, the rest
@@ -128,12 +128,17 @@ static_assert(WS_FT + 14 * WS_DPW <= 240, "transform slots");
 
 // MODE: 0 no transform, 1 affine (per utterance, channel) + x*sigmoid(x), 2 normalisation-backward
 // prologue (nb_*: d y = c1*dz + c2*y + c3 [* (y > 0)] over two input tensors)
+// 3: mode 1 + pro_stats (per-tile sum / sum of squares of the transformed rows the tile owns),
+// 4: mode 1 + a second, per-channel affine (the classifier's input BatchNorm behind the activation)
 template <int MODE>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1)))
 void sa_conv_ws_kernel(SaConvArgs a, int tiles_per_wg, int total_tiles) {
   constexpr bool PRO2 = MODE == 2;
+  constexpr bool SWISH = MODE == 1 || MODE == 3 || MODE == 4;   // affine (per utterance, channel) + x*sigmoid(x)
+  constexpr bool PSTAT = MODE == 3, AFF2 = MODE == 4;
+  constexpr bool COLRED = PRO2 || PSTAT;                    // per-tile column reductions through the LDS scratch
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  // LDS: [operand buffer 0][operand buffer 1][raw tile x][raw tile nb_x (PRO2)][column-sum scratch (PRO2)]
+  // LDS: [operand buffer 0][operand buffer 1][raw tile x][raw tile nb_x (PRO2)][column-reduction scratch (PRO2, pro_stats)]
   bf16_t* const planes = reinterpret_cast<bf16_t*>(smem);
   unsigned char* const raw = smem + 2 * WS_BUF_BYTES;
   const unsigned raw_lds = (unsigned)(uintptr_t)(lds_byte*)raw;
@@ -200,14 +205,22 @@ void sa_conv_ws_kernel(SaConvArgs a, int tiles_per_wg, int total_tiles) {
   };
 
   // per-utterance transform constants (reloaded when the tile range crosses an utterance)
-  float s1[4], t1[4], k1[4], k2[4], k3[4];
+  float s1[4], t1[4], k1[4], k2[4], k3[4], s2[4], t2[4];
   int cur_b = -1;
+  if constexpr (AFF2) {                                     // per channel: loaded once
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      s2[j] = a.s2[(lane_ & 31) * 4 + j];
+      t2[j] = a.t2 ? a.t2[(lane_ & 31) * 4 + j] : 0.0f;
+      asm volatile("" : "+v"(s2[j]), "+v"(t2[j]));
+    }
+  }
   auto load_consts = [&](int b) {
     WS_IDS;
     const int ch = (lane & 31) * 4;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-      if constexpr (MODE == 1) {
+      if constexpr (SWISH) {
         s1[j] = a.s1[(size_t)b * WS_C + ch + j];
         t1[j] = a.t1[(size_t)b * WS_C + ch + j];
       }
@@ -218,7 +231,7 @@ void sa_conv_ws_kernel(SaConvArgs a, int tiles_per_wg, int total_tiles) {
     }
 #pragma unroll
     for (int j = 0; j < 4; ++j) {                          // waited for here, not in the filler slots
-      if constexpr (MODE == 1) asm volatile("" : "+v"(s1[j]), "+v"(t1[j]));
+      if constexpr (SWISH) asm volatile("" : "+v"(s1[j]), "+v"(t1[j]));
       if constexpr (PRO2) asm volatile("" : "+v"(k1[j]), "+v"(k2[j]), "+v"(k3[j]));
     }
     cur_b = b;
@@ -256,10 +269,7 @@ void sa_conv_ws_kernel(SaConvArgs a, int tiles_per_wg, int total_tiles) {
 
   // ---- transform of a piece, in sub-steps (each small enough for one filler slot) ----
   f32x4 vx[1], vy[1];                                      // the raw piece being transformed (the next one is read as soon as stage 0 has consumed it)
-  float f[4], csum[4];
-#ifdef SA_WS_DBG_BITS
-  float dbgv[4];                                           // diagnostic: a stage value whose low 16 bits go to a_out
-#endif
+  float f[4], csum[4], csq[4];
   uint2 phi, plo;                                          // hi / lo bf16 quadruples of the piece
   unsigned pl_cur = 0;                                     // LDS byte offset of this lane's first row in the transform tile's buffer
   auto piece_read = [&](int j, int part = 2) {              // 0: x, 1: nb_x (PRO2), 2: both
@@ -277,7 +287,11 @@ void sa_conv_ws_kernel(SaConvArgs a, int tiles_per_wg, int total_tiles) {
   // is this lane's row of piece j one the tile owns (operand cache, column sums)?  interior tiles:
   // every piece but the two halo pieces (i = 0: rows -2, -1; i = 33: rows 64, 65), a wave-uniform test
   auto owns = [&](Tile T, bool edge, int j) -> bool {
-    if (!edge) return (j != 0 || wave_ != 0) && (j != WS_DPW - 1 || wave_ != (WS_NDMA - 1) % 4);
+    if (!edge) {                                           // own rows = staged rows [-rowmin, -rowmin + 64): whole pieces
+      const int i = wave_ + 4 * j, lo = -a.rowmin >> 1;    // (rowmin is even: checked at launch)
+      if (j > 0 && j < WS_DPW - 2) return true;            // pieces 4..27 are owned in every geometry
+      return i >= lo && i < lo + WS_TM / 2;
+    }
     int lo, hi;
     own_range(T, lo, hi);
     const int g = T.tile * WS_TM + a.rowmin + (int)row0 + 8 * j;
@@ -295,21 +309,13 @@ void sa_conv_ws_kernel(SaConvArgs a, int tiles_per_wg, int total_tiles) {
   auto piece_elem = [&](Tile T, bool edge, int j, int q) {            // channel q of the lane's four
     if (j == WS_DPW - 1 && wave_ + 4 * j >= WS_NDMA) return;
     float v = vx[0][q];
-    if constexpr (MODE == 1) {                             // the very operations of piece_stage: a row's operand
+    if constexpr (SWISH) {                                 // the very operations of piece_stage: a row's operand
       const float zz = fmaf(v, s1[q], t1[q]);              // must not depend on which path staged it
-#if defined(SA_WS_EXP2)
-      v = zz;
-#elif defined(SA_WS_EXP3)
-      v = __builtin_amdgcn_exp2f(zz * -1.4426950408889634f);
-#elif defined(SA_WS_DBG_BITS)
-      {
-        const float e_ = __builtin_amdgcn_exp2f(zz * -1.4426950408889634f), d_ = 1.0f + e_, r_ = __builtin_amdgcn_rcpf(d_);
-        v = zz * r_;
-        dbgv[q] = SA_WS_DBG_BITS == 1 ? zz : SA_WS_DBG_BITS == 2 ? e_ : SA_WS_DBG_BITS == 3 ? d_ : SA_WS_DBG_BITS == 4 ? r_ : v;
-      }
-#else
       v = zz * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(zz * -1.4426950408889634f));
-#endif
+      if constexpr (AFF2) v = fmaf(v, s2[q], t2[q]);
+      if constexpr (PSTAT) {
+        if (owns(T, edge, j)) { csum[q] += v; csq[q] = fmaf(v, v, csq[q]); }
+      }
     }
     if constexpr (PRO2) {
       const float y = vy[0][q];
@@ -335,28 +341,13 @@ void sa_conv_ws_kernel(SaConvArgs a, int tiles_per_wg, int total_tiles) {
     for (int q = 2 * h; q < 2 * h + 2; ++q) {
       if constexpr (MODE == 0) {
         if (st == 0) f[q] = vx[0][q];
-      } else if constexpr (MODE == 1) {                    // x*sigmoid(x), the operations of sa_swish
-#if defined(SA_WS_EXP2)                                    // diagnostic: affine only
-        if (st == 0) f[q] = fmaf(vx[0][q], s1[q], t1[q]);
-#elif defined(SA_WS_EXP3)                                  // diagnostic: affine + exp2 only
-        if (st == 0) f[q] = __builtin_amdgcn_exp2f(fmaf(vx[0][q], s1[q], t1[q]) * -1.4426950408889634f);
-#elif defined(SA_WS_EXP1)
-        if (st == 0) { const float zz = fmaf(vx[0][q], s1[q], t1[q]); f[q] = zz * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(zz * -1.4426950408889634f)); }
-#else
+      } else if constexpr (SWISH) {                        // x*sigmoid(x), the operations of sa_swish
         if (st == 0) { z[q] = fmaf(vx[0][q], s1[q], t1[q]); w[q] = z[q] * -1.4426950408889634f; }
         if (st == 1) w[q] = 1.0f + __builtin_amdgcn_exp2f(w[q]);
-#if defined(SA_WS_DBG_BITS)
         if (st == 2) {
-          const float r_ = __builtin_amdgcn_rcpf(w[q]);
-          f[q] = z[q] * r_;
-          dbgv[q] = SA_WS_DBG_BITS == 1 ? z[q] : SA_WS_DBG_BITS == 2 ? w[q] - 1.0f : SA_WS_DBG_BITS == 3 ? w[q] : SA_WS_DBG_BITS == 4 ? r_ : f[q];
+          f[q] = z[q] * __builtin_amdgcn_rcpf(w[q]);
+          if constexpr (AFF2) f[q] = fmaf(f[q], s2[q], t2[q]);
         }
-#elif defined(SA_WS_EXP4)
-        if (st == 2) { w[q] = __builtin_amdgcn_rcpf(w[q]); if (q == 2 * h + 1) { asm volatile("s_nop 3" : "+v"(w[2 * h]), "+v"(w[2 * h + 1])); f[2 * h] = z[2 * h] * w[2 * h]; f[q] = z[q] * w[q]; } }
-#else
-        if (st == 2) f[q] = z[q] * __builtin_amdgcn_rcpf(w[q]);
-#endif
-#endif
       } else {
         if (st == 0) { z[q] = fmaf(k2[q], vy[0][q], k3[q]); f[q] = fmaf(k1[q], vx[0][q], z[q]); }
         if (st == 1) { if (a.nb_relu_mask) f[q] = vy[0][q] > 0.0f ? f[q] : 0.0f; }
@@ -368,6 +359,15 @@ void sa_conv_ws_kernel(SaConvArgs a, int tiles_per_wg, int total_tiles) {
       else split_pair(f[2], f[3], phi.y, plo.y);
     }
   };
+  auto piece_pstat = [&](Tile T, int j) {                   // pro_stats of an interior tile's piece (slot form)
+    if constexpr (PSTAT) {
+      if (j == WS_DPW - 1 && wave_ + 4 * j >= WS_NDMA) return;
+      if (owns(T, false, j)) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { csum[q] += f[q]; csq[q] = fmaf(f[q], f[q], csq[q]); }
+      }
+    }
+  };
   auto piece_write = [&](int j, int part = 2) {             // operand planes of the transform tile (0 hi, 1 lo, 2 both)
     if (j == WS_DPW - 1 && wave_ + 4 * j >= WS_NDMA) return;
     unsigned char* dst = smem + (pl_cur + j * (8 * WS_PITCH * 2));
@@ -376,37 +376,40 @@ void sa_conv_ws_kernel(SaConvArgs a, int tiles_per_wg, int total_tiles) {
   };
   auto piece_cache = [&](Tile T, bool edge, int j) {          // bf16 operand cache for sa_wgrad: hi values of the owned rows
     if (j == WS_DPW - 1 && wave_ + 4 * j >= WS_NDMA) return;
-#if defined(SA_WS_DBG_BITS)
-    if (has_ao && owns(T, edge, j))
-      ws_store_b64(aobase_t + j * (8 * WS_C * 2), ao_off,
-                   make_uint2((__float_as_uint(dbgv[0]) & 0xffffu) | (__float_as_uint(dbgv[1]) << 16),
-                              (__float_as_uint(dbgv[2]) & 0xffffu) | (__float_as_uint(dbgv[3]) << 16)));
-#elif defined(SA_WS_DBG_LO)                                // diagnostic build: the lo plane instead of the hi one
-    if (has_ao && owns(T, edge, j)) ws_store_b64(aobase_t + j * (8 * WS_C * 2), ao_off, plo);
-#else
     if (has_ao && owns(T, edge, j)) ws_store_b64(aobase_t + j * (8 * WS_C * 2), ao_off, phi);
-#endif
   };
-  auto colsum_put = [&](int it) {                           // PRO2: this wave's column sums -> LDS (summed after the barrier)
-    if constexpr (PRO2) {
-      if (a.nb_colsum) {
-        WS_IDS;
-        float* colred = reinterpret_cast<float*>(raw + 2 * WS_RAW_BYTES) + (size_t)(it & 1) * 4 * WS_C;
+  // per-tile column reductions of the transform (PRO2: column sums of d y; pro_stats: sum and sum of
+  // squares of the transformed rows): fold the two row halves of the wave, one LDS slot per wave,
+  // summed in wave order by 128 threads after the tile barrier
+  constexpr int NRED = PSTAT ? 2 : 1;
+  auto colsum_put = [&](int it) {
+    if constexpr (COLRED) {
+      if (PSTAT || a.nb_colsum) {
+        float* colred = reinterpret_cast<float*>(raw + (PRO2 ? 2 : 1) * WS_RAW_BYTES) + (size_t)(it & 1) * 4 * WS_C * NRED;
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-          const float v = csum[q] + __shfl_xor(csum[q], 32, 64);
-          if (lane < 32) colred[wave * WS_C + (lane & 31) * 4 + q] = v;
+          const float v = csum[q] + __int_as_float(__builtin_amdgcn_ds_bpermute((int)swap_off, __float_as_int(csum[q])));
+          if (lane_ < 32) colred[(wave_ * WS_C + (lane_ & 31) * 4 + q) * NRED] = v;
           csum[q] = 0.0f;
+          if constexpr (PSTAT) {
+            const float u = csq[q] + __int_as_float(__builtin_amdgcn_ds_bpermute((int)swap_off, __float_as_int(csq[q])));
+            if (lane_ < 32) colred[(wave_ * WS_C + (lane_ & 31) * 4 + q) * NRED + 1] = u;
+            csq[q] = 0.0f;
+          }
         }
       }
     }
   };
   auto colsum_out = [&](int t, int it) {                    // after the barrier that follows colsum_put(it)
-    if constexpr (PRO2) {
-      if (a.nb_colsum && tid < WS_C) {
-        const float* colred = reinterpret_cast<const float*>(raw + 2 * WS_RAW_BYTES) + (size_t)(it & 1) * 4 * WS_C;
-        a.nb_colsum[(size_t)t * WS_C + tid] =
-            (colred[tid] + colred[WS_C + tid]) + (colred[2 * WS_C + tid] + colred[3 * WS_C + tid]);
+    if constexpr (COLRED) {
+      if ((PSTAT || a.nb_colsum) && tid < WS_C) {
+        const float* colred = reinterpret_cast<const float*>(raw + (PRO2 ? 2 : 1) * WS_RAW_BYTES) + (size_t)(it & 1) * 4 * WS_C * NRED;
+        float* dst = PSTAT ? a.pro_stats : a.nb_colsum;
+#pragma unroll
+        for (int r = 0; r < NRED; ++r)
+          dst[((size_t)t * WS_C + tid) * NRED + r] =
+              (colred[tid * NRED + r] + colred[(WS_C + tid) * NRED + r]) +
+              (colred[(2 * WS_C + tid) * NRED + r] + colred[(3 * WS_C + tid) * NRED + r]);
       }
     }
   };
@@ -469,7 +472,7 @@ void sa_conv_ws_kernel(SaConvArgs a, int tiles_per_wg, int total_tiles) {
   // slots then repeat that tile's work (same values to the same places) instead of branching.
   Tile Tc = tile_of(first), Tn = tile_of(first + 1 < last ? first + 1 : last - 1), Tp = Tc;
 #pragma unroll
-  for (int q = 0; q < 4; ++q) csum[q] = 0.0f;
+  for (int q = 0; q < 4; ++q) { csum[q] = 0.0f; csq[q] = 0.0f; }
   {
     const bool ec = is_edge(Tc), en = is_edge(Tn);
     xbase_d = row_block(a.x, Tc.b, a.Lin, Tc.tile * WS_TM + a.rowmin, WS_C * 4);
@@ -480,7 +483,7 @@ void sa_conv_ws_kernel(SaConvArgs a, int tiles_per_wg, int total_tiles) {
     for (int j = 0; j < WS_DPW; ++j) dma_piece(Tc, ec, j);
     xbase_d = row_block(a.x, Tn.b, a.Lin, Tn.tile * WS_TM + a.rowmin, WS_C * 4);
     if constexpr (PRO2) x2base_d = row_block(a.nb_x, Tn.b, a.Lin, Tn.tile * WS_TM + a.rowmin, WS_C * 4);
-    if (MODE != 0) load_consts(Tc.b);
+    if (SWISH || PRO2) load_consts(Tc.b);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #pragma unroll
     for (int j = 0; j < WS_DPW; ++j) {
@@ -511,7 +514,7 @@ void sa_conv_ws_kernel(SaConvArgs a, int tiles_per_wg, int total_tiles) {
     // training length) gets its masked transform / clamped DMA after the loop, a partial output tile
     // its bounds-checked epilogue in front of it, not overlapped
     const bool slotE = doE && !partialE, slotT = !edgeT, slotD = !edgeT && !edgeD;
-    if (MODE != 0 && Tn.b != cur_b) load_consts(Tn.b);
+    if ((SWISH || PRO2) && Tn.b != cur_b) load_consts(Tn.b);
     xbase_d = row_block(a.x, Tnn.b, a.Lin, Tnn.tile * WS_TM + a.rowmin, WS_C * 4);
     if constexpr (PRO2) x2base_d = row_block(a.nb_x, Tnn.b, a.Lin, Tnn.tile * WS_TM + a.rowmin, WS_C * 4);
     aobase_t = const_cast<char*>(row_block(a.a_out, Tn.b, a.Lin, Tn.tile * WS_TM + a.rowmin, WS_C * 2));
@@ -564,6 +567,7 @@ void sa_conv_ws_kernel(SaConvArgs a, int tiles_per_wg, int total_tiles) {
           if constexpr (j + 1 < WS_DPW && k == 3 && PRO2) piece_read(j + 1, 1);
           if constexpr (k == 8 || k == 9) piece_write(j, h);
           if constexpr (k == 10) piece_cache(Tn, false, j);
+          if constexpr (k == 11) piece_pstat(Tn, j);
           if constexpr (k == 12 || (k == 13 && PRO2)) dma_piece(Tnn, false, j, h);
         }
       };
@@ -620,11 +624,7 @@ void sa_conv_ws_kernel(SaConvArgs a, int tiles_per_wg, int total_tiles) {
 #undef WS_AH
       });
     };
-#ifdef SA_WS_NOFAST                                        // diagnostic build: every tile through the un-overlapped path
-    const bool fast = false;
-#else
     const bool fast = slotE && slotT && slotD;
-#endif
     if (fast) {
       tile_body(std::true_type{});
     } else {
@@ -699,11 +699,11 @@ int launch_ws(const SaConvArgs& a, hipStream_t st) {
   args.rowmin = omin;
   args.nrows = WS_ROWS;
   args.wlo_off = (wmax + 1) * WS_KSTEPS * 4 * 64;        // fragment units: size of the hi image
-  if ((a.a_out || a.nb_colsum) &&
+  if ((a.a_out || a.nb_colsum || a.pro_stats) &&
       (omin > 0 || omax < 0 || (args.ntiles - 1) * WS_TM + omin + WS_ROWS < a.Lin))
     return -22;                                           // every input row must be staged by the tile that owns it
   if ((long)a.B * a.Lin >= (1L << 31) - 64 || (long)a.B * a.Lout >= (1L << 31) - 64) return -22;   // 32-bit row indices in the kernel
-  const size_t lds = 2 * WS_BUF_BYTES + (MODE == 2 ? 2 : 1) * WS_RAW_BYTES + (MODE == 2 ? 2 * 4 * WS_C * 4 : 0);
+  const size_t lds = 2 * WS_BUF_BYTES + (MODE == 2 ? 2 : 1) * WS_RAW_BYTES + (MODE == 2 ? 2 * 4 * WS_C * 4 : MODE == 3 ? 2 * 4 * WS_C * 8 : 0);
   auto kern = sa_conv_ws_kernel<MODE>;
   static bool attr_set = false;
   static int n_cu = 0;
@@ -730,7 +730,9 @@ int launch_ws(const SaConvArgs& a, hipStream_t st) {
 // Does the weight-stationary kernel serve this launch?  (sa_conv_gemm.hip asks before routing.)
 bool sa_conv_ws_covers(int dtype, int cin, int cout, int sa, int u, const SaConvArgs* a) {
   if (dtype != SA_BF16X3 || cin != WS_C || cout != WS_C || sa != 1 || u != 1) return false;
-  if (a->taps.ntaps[0] != WS_NTAPS || a->pro_stats || a->s2 || a->t2 || a->wscale) return false;
+  if (a->taps.ntaps[0] != WS_NTAPS || a->wscale) return false;
+  if ((a->s2 || a->t2) && (!a->s2 || !a->s1 || a->pro_stats)) return false;    // second affine: behind affine + activation only
+  if (a->pro_stats && (!a->s1 || a->nb_x)) return false;
   if (a->ep_mode) return false;
   int omin = 1 << 30, omax = -(1 << 30);
   for (int t = 0; t < WS_NTAPS; ++t) {
@@ -738,9 +740,9 @@ bool sa_conv_ws_covers(int dtype, int cin, int cout, int sa, int u, const SaConv
     omax = a->taps.off[0][t] > omax ? a->taps.off[0][t] : omax;
   }
   if (omax - omin != WS_HALO) return false;               // 5 taps at unit spacing
-  // the slots' ownership test (operand cache, column sums) is written for the 'same'-padding
-  // geometry: two halo rows on either side = the first and the last DMA piece of a tile
-  if ((a->a_out || a->nb_colsum) && omin != -2) return false;
+  // the slots' ownership test (operand cache, column sums, pro_stats) works on whole DMA pieces (row
+  // pairs): the tile's own rows must start at an even staged row
+  if ((a->a_out || a->nb_colsum || a->pro_stats) && (omin > 0 || (omin & 1))) return false;
   if (a->tile_rows && a->tile_rows != WS_TM) return false;
 #ifndef SA_WS_PRO2
   if (a->nb_x) return false;                              // data gradients stay on the one-tile kernel (header)
@@ -755,6 +757,8 @@ int sa_conv_ws_dispatch(const SaConvArgs* a, hipStream_t st) {
 #ifdef SA_WS_PRO2                                         // experiment build: MODE 2 without a fused epilogue
   if (a->nb_x) return launch_ws<2>(*a, st);
 #endif
+  if (a->s1 && a->pro_stats) return launch_ws<3>(*a, st);
+  if (a->s1 && a->s2) return launch_ws<4>(*a, st);
   if (a->s1) return launch_ws<1>(*a, st);
   return launch_ws<0>(*a, st);
 }

@@ -659,7 +659,7 @@ def test_pingpong_conv_kernel_in_the_model():
 
 
 @pytest.mark.parametrize("Ln,pad", [(20160, 2), (20001, 2), (20164, 0)], ids=["train", "ragged", "valid"])
-@pytest.mark.parametrize("mode", ["plain", "swish_stats_cache", "relu_stats"])
+@pytest.mark.parametrize("mode", ["plain", "swish_stats_cache", "relu_stats", "pro_stats", "two_affine"])
 def test_weight_stationary_conv_kernel(mode, Ln, pad):
     """sa_conv_ws.hip (persistent, weights in registers, rows by LDS-DMA, epilogue / transform in the
     MFMA loop's issue gaps) serves the large 128->128 bf16x3 forward launches: same output BITS as the
@@ -677,15 +677,21 @@ def test_weight_stationary_conv_kernel(mode, Ln, pad):
     wp = ops.pack_weights(w, "conv_fwd", torch.float32, L.BF16X3)
     Lout = Ln + 2 * pad - 4
     kw = dict(code=L.BF16X3)
+    s2 = (torch.rand(128, generator=g) + 0.5).to(d)
+    t2 = (torch.randn(128, generator=g) * 0.1).to(d)
+    cached = mode in ("swish_stats_cache", "pro_stats", "two_affine")
     if mode == "swish_stats_cache":
         kw.update(s1=s1, t1=t1, swish=True, want_stats=True)
     elif mode == "relu_stats":
         kw.update(relu=True, want_stats=True)
+    elif mode == "pro_stats":                    # decoder.0: also the statistics of its own transformed input
+        kw.update(s1=s1, t1=t1, swish=True, want_pro_stats=True)
+    elif mode == "two_affine":                   # the classifier's first TDNN layer: BatchNorm behind the activation, ReLU out
+        kw.update(s1=s1, t1=t1, swish=True, s2=s2, t2=t2, relu=True, want_stats=True)
 
     def run(ws):
         ops.conv_impl(ws=ws)
-        a_out = torch.full((B, Ln, 128), float("nan"), dtype=torch.bfloat16, device=d) if mode == "swish_stats_cache" else None
-        a = L.SaConvArgs()
+        a_out = torch.full((B, Ln, 128), float("nan"), dtype=torch.bfloat16, device=d) if cached else None
         r = ops.conv_gemm(x, wp, bias if mode != "plain" else None, 128, 128, 1, 1, ops.taps_conv(5, 1, pad), Lout,
                           a_out=a_out, **kw)
         torch.cuda.synchronize()
@@ -696,14 +702,22 @@ def test_weight_stationary_conv_kernel(mode, Ln, pad):
     finally:
         ops.conv_impl()
     assert torch.equal(ref[0], got[0])                               # y: bit-equal
-    if mode != "plain":
+    if mode != "plain":                                              # statistics / pro_stats slabs
         assert ref[1].shape == got[1].shape and torch.allclose(ref[1], got[1], rtol=2e-6, atol=1e-3)
-    if mode == "swish_stats_cache":
+    if cached:
         assert not torch.isnan(got[2].float()).any() and torch.equal(ref[2], got[2])
-    xin = torch.nn.functional.silu(x * s1[:, None, :] + t1[:, None, :]) if mode == "swish_stats_cache" else x
+    xin = x
+    if cached:
+        xin = torch.nn.functional.silu(x * s1[:, None, :] + t1[:, None, :])
+        if mode == "two_affine":
+            xin = xin * s2 + t2
     yref = F.conv1d(xin.permute(0, 2, 1), w, bias if mode != "plain" else None, padding=pad).permute(0, 2, 1)
-    if mode == "relu_stats":
+    if mode in ("relu_stats", "two_affine"):
         yref = yref.relu()
+    if mode == "pro_stats":                                          # (sum, sumsq) of the transformed input per utterance, channel
+        ps = got[1].double().sum(dim=1)
+        assert torch.allclose(ps[..., 0], xin.double().sum(dim=1), rtol=1e-5, atol=1e-2)
+        assert torch.allclose(ps[..., 1], (xin.double() ** 2).sum(dim=1), rtol=1e-5, atol=1e-2)
     assert rel_mse(got[0], yref) < 2e-9
 
 
