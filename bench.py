@@ -58,6 +58,8 @@ def parse_args(argv=None):
                          "Measured equal to eager (B = 32: 9.95 vs 9.88 ms, B = 10: 3.96 vs 3.96 ms) once the "
                          "per-step host synchronisation was gone, so eager is the default")
     ap.add_argument("--master-port", type=int, default=0)
+    ap.add_argument("--conv-impl", default="default", choices=["default", "one-tile", "pingpong"],
+                    help="A/B timing of the conv kernels (default: weight-stationary where it covers)")
     return ap.parse_args(argv)
 
 
@@ -200,6 +202,7 @@ def run_config(args, batch_size, rank, world, device, profile_key=None):
     dominant kernel, graph mode, host time spent issuing one step)."""
     import torch
     from speech_anonymization_amd import ops
+    ops.conv_impl(pingpong=args.conv_impl == "pingpong", ws=args.conv_impl == "default")
     graph = world == 1 and args.graph
     brain = build_brain(device, args.dtype, batch_size, hip_graph=graph)
     batch = synthetic_batch(batch_size, rank, device, args.samples)
