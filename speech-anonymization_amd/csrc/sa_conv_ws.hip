@@ -54,17 +54,29 @@ namespace {
 
 constexpr int WS_C = 128;                  // channels in = channels out
 constexpr int WS_TM = 64;                  // output rows per tile
-constexpr int WS_NTAPS = 5;
-constexpr int WS_HALO = 4;                 // largest - smallest tap offset
-constexpr int WS_ROWS = WS_TM + WS_HALO;   // staged input rows per tile
 constexpr int WS_KSTEPS = WS_C / 16;
 constexpr int WS_PITCH = WS_C + 8;         // bf16 elements per LDS operand row (272 B: conflict-free ds_read_b128)
-constexpr int WS_PLANE = WS_ROWS * WS_PITCH;            // bf16 elements per plane
-constexpr int WS_NDMA = WS_ROWS / 2;       // 1-KiB DMA pieces (2 rows each) per tile and tensor
-constexpr int WS_DPW = (WS_NDMA + 3) / 4;  // pieces per wave (waves 0,1: 9; waves 2,3: 8)
-constexpr int WS_RAW_BYTES = WS_ROWS * WS_C * 4;        // one raw fp32 tile
-constexpr int WS_BUF_BYTES = 2 * WS_PLANE * 2;          // one operand buffer (hi + lo planes)
-constexpr int WS_NAGPR_FRAGS = 32;         // (tap, k-step) pairs whose hi + lo weight fragments live in AGPRs (all 256)
+
+// geometry of one instantiation: NT taps spanning HALO rows (5 taps at unit spacing: 4; the dilated
+// 3-tap TDNN layers: 4 and 6)
+template <int NT, int HALO_>
+struct WsGeo {
+  static constexpr int NTAPS = NT, HALO = HALO_;
+  static constexpr int ROWS = WS_TM + HALO_;               // staged input rows per tile
+  static constexpr int PLANE = ROWS * WS_PITCH;            // bf16 elements per plane
+  static constexpr int NDMA = ROWS / 2;                    // 1-KiB DMA pieces (2 rows each) per tile and tensor
+  static constexpr int DPW = (NDMA + 3) / 4;               // pieces per wave (the last waves have one less)
+  static constexpr int RAW_BYTES = ROWS * WS_C * 4;        // one raw fp32 tile
+  static constexpr int BUF_BYTES = 2 * PLANE * 2;          // one operand buffer (hi + lo planes)
+  // (tap, k-step) pairs whose hi + lo weight fragments live in AGPRs (at most all 256 of them)
+  static constexpr int NAGPR_FRAGS = NT * WS_KSTEPS < 32 ? NT * WS_KSTEPS : 32;
+  static constexpr int NSLOT = NT * WS_KSTEPS * 6;         // MFMAs = filler slots per tile
+  // slots per piece of the transform: 14 (three arithmetic stages, two channel pairs each) where the
+  // tile has 240 slots, 7 (one stage) for the 3-tap layers' 144
+  static constexpr int SUBS = NT == 5 ? 14 : 7;
+  static constexpr int FT = NSLOT - SUBS * DPW;            // first transform slot
+  static_assert(FT > 67, "epilogue slots");
+};
 
 typedef __attribute__((address_space(3))) unsigned char lds_byte;
 
@@ -123,19 +135,24 @@ __device__ __forceinline__ void ws_static_for(F&& f) {
 //                 the tile after next
 // Tiles at the ends of an utterance (rows outside it: clamped DMA addresses, zeroed operand rows,
 // ownership checks) and partial output tiles take general, masked versions of the same slots.
-constexpr int WS_FT = 114;                 // first transform slot
-static_assert(WS_FT + 14 * WS_DPW <= 240, "transform slots");
 
 // MODE: 0 no transform, 1 affine (per utterance, channel) + x*sigmoid(x), 2 normalisation-backward
 // prologue (nb_*: d y = c1*dz + c2*y + c3 [* (y > 0)] over two input tensors)
 // 3: mode 1 + pro_stats (per-tile sum / sum of squares of the transformed rows the tile owns),
 // 4: mode 1 + a second, per-channel affine (the classifier's input BatchNorm behind the activation)
-template <int MODE>
+// 5: one per-channel affine only (the dilated TDNN layers: BatchNorm of the layer below in front)
+template <int MODE, int NT, int HALO>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1)))
 void sa_conv_ws_kernel(SaConvArgs a, int tiles_per_wg, int total_tiles) {
+  typedef WsGeo<NT, HALO> G;
+  constexpr int WS_NTAPS = G::NTAPS, WS_ROWS = G::ROWS, WS_PLANE = G::PLANE, WS_NDMA = G::NDMA, WS_DPW = G::DPW,
+                WS_RAW_BYTES = G::RAW_BYTES, WS_BUF_BYTES = G::BUF_BYTES, WS_NAGPR_FRAGS = G::NAGPR_FRAGS,
+                WS_FT = G::FT, WS_SUBS = G::SUBS;
+  (void)WS_ROWS;
+  static_assert(MODE == 0 || MODE == 5 || NT == 5, "the staged transforms need the 240-slot tile");
   constexpr bool PRO2 = MODE == 2;
   constexpr bool SWISH = MODE == 1 || MODE == 3 || MODE == 4;   // affine (per utterance, channel) + x*sigmoid(x)
-  constexpr bool PSTAT = MODE == 3, AFF2 = MODE == 4;
+  constexpr bool PSTAT = MODE == 3, AFF2 = MODE == 4 || MODE == 5;   // (mode 5: the second affine alone)
   constexpr bool COLRED = PRO2 || PSTAT;                    // per-tile column reductions through the LDS scratch
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   // LDS: [operand buffer 0][operand buffer 1][raw tile x][raw tile nb_x (PRO2)][column-reduction scratch (PRO2, pro_stats)]
@@ -317,6 +334,7 @@ void sa_conv_ws_kernel(SaConvArgs a, int tiles_per_wg, int total_tiles) {
         if (owns(T, edge, j)) { csum[q] += v; csq[q] = fmaf(v, v, csq[q]); }
       }
     }
+    if constexpr (MODE == 5) v = fmaf(v, s2[q], t2[q]);
     if constexpr (PRO2) {
       const float y = vy[0][q];
       v = fmaf(k1[q], v, fmaf(k2[q], y, k3[q]));
@@ -341,6 +359,8 @@ void sa_conv_ws_kernel(SaConvArgs a, int tiles_per_wg, int total_tiles) {
     for (int q = 2 * h; q < 2 * h + 2; ++q) {
       if constexpr (MODE == 0) {
         if (st == 0) f[q] = vx[0][q];
+      } else if constexpr (MODE == 5) {
+        if (st == 0) f[q] = fmaf(vx[0][q], s2[q], t2[q]);
       } else if constexpr (SWISH) {                        // x*sigmoid(x), the operations of sa_swish
         if (st == 0) { z[q] = fmaf(vx[0][q], s1[q], t1[q]); w[q] = z[q] * -1.4426950408889634f; }
         if (st == 1) w[q] = 1.0f + __builtin_amdgcn_exp2f(w[q]);
@@ -560,7 +580,7 @@ void sa_conv_ws_kernel(SaConvArgs a, int tiles_per_wg, int total_tiles) {
           asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
           WS_STAMP(it, 5);
           piece_read(0);
-        } else if constexpr (fs >= WS_FT) {
+        } else if constexpr (fs >= WS_FT && WS_SUBS == 14) {
           constexpr int j = (fs - WS_FT) / 14, k = (fs - WS_FT) % 14, h = k & 1;
           if constexpr (k < 8) piece_stage(Tn, j, k / 2, h);
           if constexpr (j + 1 < WS_DPW && k == 1) piece_read(j + 1, 0);    // stage 0 has consumed the raw piece
@@ -569,6 +589,14 @@ void sa_conv_ws_kernel(SaConvArgs a, int tiles_per_wg, int total_tiles) {
           if constexpr (k == 10) piece_cache(Tn, false, j);
           if constexpr (k == 11) piece_pstat(Tn, j);
           if constexpr (k == 12 || (k == 13 && PRO2)) dma_piece(Tnn, false, j, h);
+        } else if constexpr (fs >= WS_FT) {                 // one arithmetic stage: 7 slots per piece
+          constexpr int j = (fs - WS_FT) / 7, k = (fs - WS_FT) % 7;
+          if constexpr (k < 2) piece_stage(Tn, j, 0, k);
+          if constexpr (j + 1 < WS_DPW && k == 1) piece_read(j + 1, 0);
+          if constexpr (k == 2 || k == 3) piece_stage(Tn, j, 3, k - 2);
+          if constexpr (k == 4) piece_write(j);
+          if constexpr (k == 5) piece_cache(Tn, false, j);
+          if constexpr (k == 6) dma_piece(Tnn, false, j);
         }
       };
       load_al(0, 0); load_al(0, 1); load_ah(0, 0); load_ah(0, 1);
@@ -685,8 +713,10 @@ void sa_conv_ws_kernel(SaConvArgs a, int tiles_per_wg, int total_tiles) {
 #undef WS_IDS
 }
 
-template <int MODE>
+template <int MODE, int NT = 5, int HALO = 4>
 int launch_ws(const SaConvArgs& a, hipStream_t st) {
+  typedef WsGeo<NT, HALO> G;
+  constexpr int WS_NTAPS = G::NTAPS, WS_HALO = G::HALO, WS_ROWS = G::ROWS, WS_RAW_BYTES = G::RAW_BYTES, WS_BUF_BYTES = G::BUF_BYTES;
   SaConvArgs args = a;
   args.ntiles = sa_div_up(a.Lout, WS_TM);
   int omin = 1 << 30, omax = -(1 << 30), wmax = 0;
@@ -704,7 +734,7 @@ int launch_ws(const SaConvArgs& a, hipStream_t st) {
     return -22;                                           // every input row must be staged by the tile that owns it
   if ((long)a.B * a.Lin >= (1L << 31) - 64 || (long)a.B * a.Lout >= (1L << 31) - 64) return -22;   // 32-bit row indices in the kernel
   const size_t lds = 2 * WS_BUF_BYTES + (MODE == 2 ? 2 : 1) * WS_RAW_BYTES + (MODE == 2 ? 2 * 4 * WS_C * 4 : MODE == 3 ? 2 * 4 * WS_C * 8 : 0);
-  auto kern = sa_conv_ws_kernel<MODE>;
+  auto kern = sa_conv_ws_kernel<MODE, NT, HALO>;
   static bool attr_set = false;
   static int n_cu = 0;
   if (!attr_set) {
@@ -730,16 +760,16 @@ int launch_ws(const SaConvArgs& a, hipStream_t st) {
 // Does the weight-stationary kernel serve this launch?  (sa_conv_gemm.hip asks before routing.)
 bool sa_conv_ws_covers(int dtype, int cin, int cout, int sa, int u, const SaConvArgs* a) {
   if (dtype != SA_BF16X3 || cin != WS_C || cout != WS_C || sa != 1 || u != 1) return false;
-  if (a->taps.ntaps[0] != WS_NTAPS || a->wscale) return false;
-  if ((a->s2 || a->t2) && (!a->s2 || !a->s1 || a->pro_stats)) return false;    // second affine: behind affine + activation only
-  if (a->pro_stats && (!a->s1 || a->nb_x)) return false;
+  const int nt = a->taps.ntaps[0];
+  if ((nt != 5 && nt != 3) || a->wscale) return false;
   if (a->ep_mode) return false;
   int omin = 1 << 30, omax = -(1 << 30);
-  for (int t = 0; t < WS_NTAPS; ++t) {
+  for (int t = 0; t < nt; ++t) {
     omin = a->taps.off[0][t] < omin ? a->taps.off[0][t] : omin;
     omax = a->taps.off[0][t] > omax ? a->taps.off[0][t] : omax;
   }
-  if (omax - omin != WS_HALO) return false;               // 5 taps at unit spacing
+  // 5 taps over 4 rows (unit spacing); 3 taps over 4 or 6 rows (dilation 2, 3)
+  if (nt == 5 ? omax - omin != 4 : (omax - omin != 4 && omax - omin != 6)) return false;
   // the slots' ownership test (operand cache, column sums, pro_stats) works on whole DMA pieces (row
   // pairs): the tile's own rows must start at an even staged row
   if ((a->a_out || a->nb_colsum || a->pro_stats) && (omin > 0 || (omin & 1))) return false;
@@ -747,13 +777,26 @@ bool sa_conv_ws_covers(int dtype, int cin, int cout, int sa, int u, const SaConv
 #ifndef SA_WS_PRO2
   if (a->nb_x) return false;                              // data gradients stay on the one-tile kernel (header)
 #else
-  if (a->nb_x) return !a->s1 && !a->swish && a->nb_c1 && a->nb_c2 && a->nb_c3;
+  if (a->nb_x) return nt == 5 && !a->s1 && !a->swish && a->nb_c1 && a->nb_c2 && a->nb_c3;
 #endif
+  if (nt == 3)                                            // the dilated TDNN layers: per-channel affine in front, or nothing
+    return !a->s1 && !a->swish && !a->pro_stats && (a->s2 || !a->t2);
+  if ((a->s2 || a->t2) && (!a->s2 || !a->s1 || a->pro_stats)) return false;    // second affine: behind affine + activation only
+  if (a->pro_stats && !a->s1) return false;
   if (a->s1) return a->t1 && a->swish;                    // affine + x*sigmoid(x)
   return !a->swish;
 }
 
 int sa_conv_ws_dispatch(const SaConvArgs* a, hipStream_t st) {
+  if (a->taps.ntaps[0] == 3) {
+    int omin = 1 << 30, omax = -(1 << 30);
+    for (int t = 0; t < 3; ++t) {
+      omin = a->taps.off[0][t] < omin ? a->taps.off[0][t] : omin;
+      omax = a->taps.off[0][t] > omax ? a->taps.off[0][t] : omax;
+    }
+    if (omax - omin == 4) return a->s2 ? launch_ws<5, 3, 4>(*a, st) : launch_ws<0, 3, 4>(*a, st);
+    return a->s2 ? launch_ws<5, 3, 6>(*a, st) : launch_ws<0, 3, 6>(*a, st);
+  }
 #ifdef SA_WS_PRO2                                         // experiment build: MODE 2 without a fused epilogue
   if (a->nb_x) return launch_ws<2>(*a, st);
 #endif

@@ -240,8 +240,8 @@ def conv_gemm(x, wp, bias, cin, cout, sa, u, phases, Lout, s1=None, t1=None, s2=
         io = (x.numel() + y.numel()) * esz
         route = lib.sa_conv_gemm_route(kc, cin, cout, sa, u, C.byref(a))
         tname = {L.F32: "float", L.BF16: "bf16_t", L.BF16X3: "bf16x3_t", L.BF16X1F: "bf16x1f_t", L.FP8: "fp8_t"}[kc]
-        ws_mode = 0 if s1 is None else 3 if want_pro_stats else 4 if s2 is not None else 1
-        kind = (f"sa_conv_ws_kernel<{ws_mode}> ({tname}, {cin}->{cout})" if route == 2 else
+        ws_mode = (5 if s2 is not None else 0) if s1 is None else 3 if want_pro_stats else 4 if s2 is not None else 1
+        kind = (f"sa_conv_ws_kernel<{ws_mode},{ntap}> ({tname}, {cin}->{cout})" if route == 2 else
                 f"sa_conv_pp_kernel<{tname},{cin},{cout},{sa},{u}>" if route == 1 else
                 f"sa_conv_gemm_kernel<{tname},{cin},{cout},{sa},{u}{',nb prologue' if nb else ''}>")
         PROFILE.stop(e0, io + ntap * cin * cout * esz + extra,

@@ -721,6 +721,45 @@ def test_weight_stationary_conv_kernel(mode, Ln, pad):
     assert rel_mse(got[0], yref) < 2e-9
 
 
+@pytest.mark.parametrize("dil", [2, 3])
+@pytest.mark.parametrize("affine", [True, False], ids=["bn_affine", "plain"])
+def test_weight_stationary_conv_kernel_dilated(dil, affine):
+    """the 3-tap dilated TDNN layers (models/ConvAutoEncoder.py:37-43: k3 d2, k3 d3, no padding) on
+    the weight-stationary kernel: 144 MFMAs per tile, the per-channel BatchNorm affine of the layer
+    below as prologue, ReLU + statistics + operand cache; output bits == the one-tile kernel"""
+    from speech_anonymization_amd import _lib as L, ops
+    d, B, Ln = dev(), 4, 20156
+    g = torch.Generator().manual_seed(13 + dil)
+    x = torch.randn(B, Ln, 128, generator=g).to(d)
+    w = (torch.randn(128, 128, 3, generator=g) * 0.05).to(d)
+    bias = torch.randn(128, generator=g).to(d)
+    s2 = (torch.rand(128, generator=g) + 0.5).to(d)
+    t2 = (torch.randn(128, generator=g) * 0.1).to(d)
+    wp = ops.pack_weights(w, "conv_fwd", torch.float32, L.BF16X3)
+    Lout = Ln - 2 * dil
+    kw = dict(s2=s2, t2=t2) if affine else {}
+
+    def run(ws):
+        ops.conv_impl(ws=ws)
+        a_out = torch.full((B, Ln, 128), float("nan"), dtype=torch.bfloat16, device=d)
+        y, st = ops.conv_gemm(x, wp, bias, 128, 128, 1, 1, ops.taps_conv(3, dil, 0), Lout, relu=True, want_stats=True,
+                              code=L.BF16X3, a_out=a_out, **kw)
+        torch.cuda.synchronize()
+        return y, st, a_out
+
+    try:
+        ref, got = run(False), run(True)
+        a = L.SaConvArgs()
+    finally:
+        ops.conv_impl()
+    assert torch.equal(ref[0], got[0]) and torch.equal(ref[2], got[2])
+    assert not torch.isnan(got[2].float()).any()
+    assert torch.allclose(ref[1], got[1], rtol=2e-6, atol=1e-3)
+    xin = x * s2 + t2 if affine else x
+    yref = F.conv1d(xin.permute(0, 2, 1), w, bias, dilation=dil).permute(0, 2, 1).relu()
+    assert rel_mse(got[0], yref) < 2e-9
+
+
 def test_weight_stationary_conv_routing():
     """what goes to the weight-stationary kernel: bf16x3 128->128 stride-1 5-tap launches with at
     least 512 tiles and no pro_stats / second affine / fused backward epilogue / normalisation-
@@ -741,7 +780,9 @@ def test_weight_stationary_conv_routing():
     a.ep_mode = 1
     assert route() == 0
     a.ep_mode = 0
-    a.taps = L.make_taps(ops.taps_conv(3, 2, 2))
+    a.taps = L.make_taps(ops.taps_conv(3, 2, 0))                      # 3 taps over 4 rows: covered
+    assert route() == 2
+    a.taps = L.make_taps(ops.taps_conv(3, 4, 0))                      # over 8 rows: not
     assert route() == 0
     ops.conv_impl(ws=False)
     a.taps = L.make_taps(ops.taps_conv(5, 1, 2))

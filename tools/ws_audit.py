@@ -31,15 +31,15 @@ for k in kernels:
     for a in accs:
         lo, hi = map(int, re.findall(r"\d+", a))
         regs |= set(range(lo, hi + 1))
-    # one segment per unrolled tile body (240 MFMAs; the kernel has a steady-state and a generic copy)
-    if len(idx) % 240:
-        print("FINDING: MFMA count is not a multiple of 240")
+    # one segment per unrolled tile body: it starts with the two C = 0 MFMAs (one per accumulator)
+    starts = [n for n, i in enumerate(idx) if lines[i].rstrip().endswith(", 0")][0::2]
+    if not starts or starts[0] != 0:
+        print("FINDING: a tile body does not start with a C = 0 MFMA")
         bad += 1
-    for seg in range(len(idx) // 240):
-        first, last = idx[seg * 240], idx[seg * 240 + 239]
-        if not lines[first].rstrip().endswith(", 0"):
-            print("FINDING: a tile body does not start with a C = 0 MFMA")
-            bad += 1
+    bounds = starts + [len(idx)]
+    print(f"      tile bodies: {[bounds[n + 1] - bounds[n] for n in range(len(starts))]} MFMAs")
+    for seg in range(len(starts)):
+        first, last = idx[bounds[seg]], idx[bounds[seg + 1] - 1]
         in_asm = True                               # `first` sits inside an asm statement
         for i in range(first, last + 1):
             l = lines[i]
