@@ -556,7 +556,8 @@ int sa_pp_share(int cout);
 // Kernel choice.  Default (2): the 128->128 bf16x3 launches the weight-stationary kernel covers
 // (sa_conv_ws.hip: persistent, one wave per SIMD, weights in registers, rows by LDS-DMA, epilogue and
 // transform in the MFMA loop's issue gaps) go there when the launch has at least two tiles per CU --
-// 271 / 293 us against 330 / 367 us (plain / forward with cache + statistics, B = 32, r02 profiles);
+// 266 / 289 us against 330 / 367 us (plain / forward with cache + statistics), 190 against 265 us for
+// the 3-tap layers (B = 32, profiles/r02_conv_structure_experiments.md);
 // same slab geometry as this file's 64-row tiles, so nothing else changes for the caller.
 // sa_conv_gemm_set_impl(0): this file's kernel only; (1): the ping-pong kernel for f32 / bf16x3.
 bool sa_conv_ws_covers(int dtype, int cin, int cout, int sa, int u, const SaConvArgs* a);
