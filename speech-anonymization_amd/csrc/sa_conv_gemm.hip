@@ -23,6 +23,7 @@
 //              as a per-tile partial slab (deterministic two-level reduction; no atomics);
 //              data-gradient launches instead apply the activation backward and emit the
 //              normalisation-backward statistics of the layer above (`ep_*`).
+#include <type_traits>
 #include "sa_common.h"
 
 // -DSA_ABL=<mask>: timing-only ablation builds (tools/conv_ablate.py; WRONG numerics, never shipped):
@@ -407,38 +408,70 @@ __global__ __launch_bounds__(256, 2) void sa_conv_gemm_kernel(SaConvArgs a, int 
     const S* xe = a.ep_mode ? reinterpret_cast<const S*>(a.ep_x) + (size_t)b * a.Lout * COUT + c * OVEC : nullptr;
     const S* ge = (a.ep_mode && a.ep_g2) ? reinterpret_cast<const S*>(a.ep_g2) + (size_t)b * a.Lout * COUT + c * OVEC : nullptr;
     const int o0 = m0 * U;
+    // one row group of the fused backward epilogue (shared by the two loops below)
+    auto ep_rows = [&](uint4 u, const uint4& epx, const uint4& epg, int o) {
+      // mode 1: g' = (g + g2) * swish'(z), xhat from x (InstanceNorm + x*sigmoid(x) block)
+      // mode 2: g' = g + g2, xhat from x, or from swish(z) when ep_xp_is_act (BatchNorm blocks)
+      float g[OVEC], x[OVEC], g2[OVEC], xn[OVEC];
+      tr::unpack(u, g); tr::unpack(epx, x); tr::unpack(epg, g2);
+#pragma unroll
+      for (int j = 0; j < OVEC; ++j) {
+        const float z = fmaf(x[j], es1[j], et1[j]);
+        if (g2k) g2[j] = fmaf(gk1[j], g2[j], fmaf(gk2[j], sa_swish(z), gk3[j]));
+        float gg = g[j] + g2[j];
+        if (a.ep_mode == 1) gg *= sa_swish_grad(z);
+        const float xv = a.ep_xp_is_act ? sa_swish(z) : x[j];
+        xn[j] = (xv - emu[j]) * ers[j];
+        g[j] = gg;
+      }
+      u = tr::pack(g);
+      *reinterpret_cast<uint4*>(yb + (size_t)o * COUT) = u;
+      if (a.stats) {
+        tr::unpack(u, g);
+#pragma unroll
+        for (int j = 0; j < OVEC; ++j) { ssum[j] += g[j]; ssq[j] = fmaf(g[j], xn[j], ssq[j]); }
+      }
+    };
+    if (a.ep_mode && o0 + TM <= a.Lout) {
+      // Full tile: the stored forward tensor (and the optional second gradient) of row group i+2 are
+      // requested before group i is processed.  In the general loop below every load sits behind
+      // the previous group's store (y may alias them as far as hipcc knows) and behind a per-thread
+      // bounds branch: one 16-byte load in flight per thread, and the 3-4 resident workgroups wait
+      // out an HBM round trip per row group together (ablation: the epilogue cost 104 of 453 us).
+      // Two groups ahead is 16 registers; all of them ahead would be 64 and a resident workgroup.
+      auto run = [&](auto has_g2_c) {
+        constexpr bool HG = decltype(has_g2_c)::value;
+        constexpr int D = NOT < 2 ? NOT : 2;
+        uint4 px[D], pg[D];
+#pragma unroll
+        for (int d = 0; d < D; ++d) {
+          px[d] = *reinterpret_cast<const uint4*>(xe + (size_t)(o0 + r0 + d * C::RPPO) * COUT);
+          pg[d] = make_uint4(0, 0, 0, 0);
+          if constexpr (HG) pg[d] = *reinterpret_cast<const uint4*>(ge + (size_t)(o0 + r0 + d * C::RPPO) * COUT);
+        }
+#pragma unroll
+        for (int i = 0; i < NOT; ++i) {
+          const int r = r0 + i * C::RPPO, o = o0 + r;
+          const uint4 epx = px[i % D], epg = pg[i % D];
+          if (i + D < NOT) {
+            px[i % D] = *reinterpret_cast<const uint4*>(xe + (size_t)(o + D * C::RPPO) * COUT);
+            if constexpr (HG) pg[i % D] = *reinterpret_cast<const uint4*>(ge + (size_t)(o + D * C::RPPO) * COUT);
+          }
+          const uint4 u = *reinterpret_cast<const uint4*>(Os + (size_t)r * C::OPITCH + c * OVEC);
+          ep_rows(u, epx, epg, o);
+        }
+      };
+      if (ge) run(std::true_type{}); else run(std::false_type{});
+    } else {
 #pragma unroll
     for (int i = 0; i < NOT; ++i) {
       const int r = r0 + i * C::RPPO, o = o0 + r;
       if (o < a.Lout) {
         uint4 u = *reinterpret_cast<const uint4*>(Os + (size_t)r * C::OPITCH + c * OVEC);
         if (a.ep_mode) {
-          // The stored forward tensor (and the optional second gradient) are fetched here, one
-          // row group at a time: prefetching all of them before the accumulator transpose costs
-          // 64 registers and with them a resident workgroup per CU.
           const uint4 epx = *reinterpret_cast<const uint4*>(xe + (size_t)o * COUT);
           const uint4 epg = ge ? *reinterpret_cast<const uint4*>(ge + (size_t)o * COUT) : make_uint4(0, 0, 0, 0);
-          // mode 1: g' = (g + g2) * swish'(z), xhat from x (InstanceNorm + x*sigmoid(x) block)
-          // mode 2: g' = g + g2, xhat from x, or from swish(z) when ep_xp_is_act (BatchNorm blocks)
-          float g[OVEC], x[OVEC], g2[OVEC], xn[OVEC];
-          tr::unpack(u, g); tr::unpack(epx, x); tr::unpack(epg, g2);
-#pragma unroll
-          for (int j = 0; j < OVEC; ++j) {
-            const float z = fmaf(x[j], es1[j], et1[j]);
-            if (g2k) g2[j] = fmaf(gk1[j], g2[j], fmaf(gk2[j], sa_swish(z), gk3[j]));
-            float gg = g[j] + g2[j];
-            if (a.ep_mode == 1) gg *= sa_swish_grad(z);
-            const float xv = a.ep_xp_is_act ? sa_swish(z) : x[j];
-            xn[j] = (xv - emu[j]) * ers[j];
-            g[j] = gg;
-          }
-          u = tr::pack(g);
-          *reinterpret_cast<uint4*>(yb + (size_t)o * COUT) = u;
-          if (a.stats) {
-            tr::unpack(u, g);
-#pragma unroll
-            for (int j = 0; j < OVEC; ++j) { ssum[j] += g[j]; ssq[j] = fmaf(g[j], xn[j], ssq[j]); }
-          }
+          ep_rows(u, epx, epg, o);
         } else {
           *reinterpret_cast<uint4*>(yb + (size_t)o * COUT) = u;
           if (a.stats) {
@@ -449,6 +482,7 @@ __global__ __launch_bounds__(256, 2) void sa_conv_gemm_kernel(SaConvArgs a, int 
           }
         }
       }
+    }
     }
     if (a.stats) {
       __syncthreads();                               // Os fully consumed: red overlays it
