@@ -4,6 +4,8 @@ import ctypes
 import os
 import re
 
+import pytest
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
@@ -52,3 +54,17 @@ def test_missing_library_fails_loudly(monkeypatch):
         assert "no CPU fallback" in str(e)
     else:
         raise AssertionError("load() must raise when the HIP library is missing")
+
+
+def test_weight_stationary_kernel_isa_audit():
+    """sa_conv_ws.hip issues its MFMAs from inline asm, so hipcc neither knows their latency nor pads
+    hazards around them (cdna_hip_programming.md 5.7): every build is audited on the ISA -- no spills,
+    no scratch, the accumulators in ONE register block per tile body, no compiler instruction on that
+    block between a body's first and last MFMA (tools/ws_audit.py; cross-compiles, no GPU needed)."""
+    import shutil
+    import subprocess
+    import sys
+    if not shutil.which("/opt/rocm/bin/hipcc"):
+        pytest.skip("hipcc not installed")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "ws_audit.py")], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0 and "audit: clean" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
