@@ -1,9 +1,9 @@
 // Implicit-GEMM 1-D convolution on MFMA (gfx950), channels-last -- the WEIGHT-STATIONARY form of
-// the 128 -> 128 channel, stride-1, 5-tap layers in the bf16x3 policy (fp32 storage, split-bf16
-// operands): models/ConvAutoEncoder.py:150-158 (encoder 128->128 blocks) and :161-166 (decoder),
-// forward and data gradient -- 10 of the 22 conv launches of a train step and 37 % of its GPU time.
+// the 128 -> 128 channel, stride-1 FORWARD launches in the bf16x3 policy (fp32 storage, split-bf16
+// operands): models/ConvAutoEncoder.py:150-158 (encoder.11), :161-166 (decoder.0) and :33-43 (the
+// three TDNN layers of the sex classifier: 5 taps, 3 taps dilation 2, 3 taps dilation 3).
 //
-// Same operation, arguments, numerics and statistics-slab geometry as the 64-row one-tile kernel
+// Same operation, arguments, statistics-slab geometry and output BITS as the 64-row one-tile kernel
 // (sa_conv_gemm.hip); different execution structure, chosen from the measurements in
 // profiles/r02_conv_structure_experiments.md (the one-tile kernel's phases do not overlap: row loads
 // 76 us + weight-fragment stream 61 us + MFMA 122 us + epilogue 37 us + launch floor 45 us):
@@ -11,24 +11,33 @@
 //   * ONE persistent 4-wave workgroup per CU (one wave per SIMD, the whole 512-register file per
 //     lane); a workgroup walks a contiguous range of 64-row tiles.
 //   * The weights never move: wave w owns output columns [32w, 32w+32) and keeps its B fragments
-//     for all 5 taps x 128 input channels x (hi, lo) = 80 fragments = 320 registers for the whole
-//     launch (the one-tile kernel re-streams 327 KB of fragments from L2 per tile).
-//   * Input rows arrive by LDS-DMA (global_load_lds_dwordx4, no register destination): the DMA of
-//     tile g+1 is issued before the MFMA loop of tile g and has that whole loop to land, so no wave
-//     ever waits on HBM; the only global loads of the loop are these.
-//   * Transform (normalisation affine + x*sigmoid(x), hi/lo split) goes LDS raw -> registers ->
-//     LDS operand planes (double-buffered: one barrier per tile); the epilogue goes straight from
-//     the accumulator registers (a register of a 32x32 accumulator = two 128-byte row segments).
+//     for all taps x 128 input channels x (hi, lo) -- 80 fragments = 320 registers with 5 taps -- for
+//     the whole launch (the one-tile kernel re-streams 327 KB of fragments from L2 per tile); 256 of
+//     them are AGPRs, read directly by MFMAs issued from inline asm.
+//   * Input rows arrive by LDS-DMA (global_load_lds_dwordx4, no register destination), two tiles
+//     ahead of the MFMA loop that consumes them.
+//   * A wave issues one instruction per 4 cycles and a 32x32x16 MFMA holds the matrix pipe for 32:
+//     a tile is 240 (144) single-MFMA statements with a FILLER SLOT of up to ~7 instructions behind
+//     each.  The slots of tile t's loop hold the epilogue of tile t-1 (from an asm copy of its
+//     accumulators; a register of a 32x32 accumulator = two 128-byte row segments per store), the
+//     transform of tile t+1 (raw LDS -> registers -> hi / lo operand planes, cut by arithmetic stage
+//     so that a slot holds independent instructions) and the refill DMA of tile t+2.  One barrier
+//     and one s_waitcnt vmcnt(0) per tile, the latter where everything outstanding is a microsecond
+//     old.
+//   * Tiles at the ends of an utterance (clamped DMA addresses, zeroed rows, ownership tests),
+//     partial output tiles and a workgroup's first tile take a plain path without overlap.
 //
-//   per tile g, per wave:   wait DMA(g) | transform(g) -> planes[g&1] | issue DMA(g+1) |
-//                           epilogue(g-1) from registers | barrier | MFMA(g)
+// tools/ws_audit.py (ISA audit, also a CPU test), tools/ws_slots.py (instructions per slot),
+// tools/ws_stamps.py (-DSA_WS_STAMPS: cycles per phase), tools/ws_check.py (bits against the
+// one-tile kernel).
 //
-// Launches it does not cover stay on sa_conv_gemm.hip: 3-tap / dilated taps (the other two TDNN
-// layers) and the data gradients.  A fused data gradient reads two more fp32 tiles per output tile (the stored
-// forward tensor for the normalisation-backward prologue, and it again + a second gradient in the
-// backward epilogue): 70 KB more LDS or 64 more registers per lane than this structure has left
-// (512 registers: 320 weights, 64 accumulators + their epilogue copy, 24 A fragments, the rest
-// transform state).  The prologue alone (MODE 2) is kept, bit-equal, behind -DSA_WS_PRO2.
+// Launches it does not cover stay on sa_conv_gemm.hip: the data gradients.  A fused data gradient
+// reads two more fp32 tiles per output tile (the stored forward tensor for the normalisation-backward
+// prologue, and it again + a second gradient in the backward epilogue): 70 KB more LDS or 64 more
+// registers per lane than this structure has left (512 registers: 320 weights, 64 accumulators +
+// their epilogue copy, 24 A fragments, the rest transform state), and with one wave per SIMD its
+// heavier transform and epilogue would be instruction-issue-bound.  The prologue alone (MODE 2) is
+// kept, bit-equal, behind -DSA_WS_PRO2.
 #include <type_traits>
 #include "sa_conv_cfg.h"
 
@@ -196,7 +205,7 @@ void sa_conv_ws_kernel(SaConvArgs a, int tiles_per_wg, int total_tiles) {
 
   // ---- lane constants of the filler slots (made opaque so that hipcc keeps THESE and derives the
   // per-slot addresses from them by immediates, instead of hoisting one address chain per slot) ----
-  const int half_ = lane_ >> 5, l31_ = lane_ & 31;
+  const int half_ = lane_ >> 5, l31_ = lane_ & 31;             // row of the piece's two, channel quad
   // this wave's piece j is piece i = wave + 4j of the tile: rows 2i + half, i.e. row (2 wave + half) + 8j
   unsigned row0 = 2 * wave_ + half_;
   unsigned dma_off = row0 * (WS_C * 4) + l31_ * 16;        // byte offset in the row block of a tile (x, nb_x): + j*4096
