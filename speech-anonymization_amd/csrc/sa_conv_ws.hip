@@ -80,11 +80,14 @@ struct WsGeo {
   // (tap, k-step) pairs whose hi + lo weight fragments live in AGPRs (at most all 256 of them)
   static constexpr int NAGPR_FRAGS = NT * WS_KSTEPS < 32 ? NT * WS_KSTEPS : 32;
   static constexpr int NSLOT = NT * WS_KSTEPS * 6;         // MFMAs = filler slots per tile
-  // slots per piece of the transform: 14 (three arithmetic stages, two channel pairs each) where the
-  // tile has 240 slots, 7 (one stage) for the 3-tap layers' 144
-  static constexpr int SUBS = NT == 5 ? 14 : 7;
+  // slots per piece of the transform: 18 where the tile has 240 slots (up to seven arithmetic
+  // levels), 12 (one level) for the 3-tap layers' 144.  Multiples of a step's six slots: the LDS
+  // instructions of a piece (raw read, operand-plane writes) then always sit in slots 0 / 1 of a step,
+  // four MFMAs ahead of the lgkmcnt(0) that hipcc puts in front of the next step's first MFMA.  The
+  // epilogue takes slots 0..33 (one accumulator register per slot, then the statistics).
+  static constexpr int SUBS = NT == 5 ? 18 : 12;
   static constexpr int FT = NSLOT - SUBS * DPW;            // first transform slot
-  static_assert(FT > 67, "epilogue slots");
+  static_assert(FT > 34 && FT % 6 == 0, "epilogue slots / step alignment");
 };
 
 typedef __attribute__((address_space(3))) unsigned char lds_byte;
@@ -130,21 +133,22 @@ __device__ __forceinline__ void ws_static_for(F&& f) {
 }
 
 // Filler slots.  With one wave per SIMD a wave issues one instruction (of any kind) per 4 cycles, a
-// 32x32x16 MFMA holds the matrix pipe for 32: the MFMA loop of a tile is 120 asm statements of two
-// MFMAs, and the gap after statement n ("slot n") takes about a dozen instructions of OTHER tiles'
-// work without delaying statement n+1 -- 1 920 issue slots per tile, 240 MFMAs + 160 fragment reads
-// of its own.  So the fillers are written to the instruction: lane offsets, LDS addresses and store
-// offsets are set up once per kernel / tile, every slot is base + immediate.
+// 32x32x16 MFMA holds the matrix pipe for 32: the MFMA loop of a tile is 240 (3 taps: 144) single-MFMA
+// asm statements, and the gap behind statement f ("slot f") takes about seven instructions of OTHER
+// tiles' work without delaying statement f+1.  So the fillers are written to the instruction: lane
+// offsets, LDS addresses and store offsets are set up once per kernel / tile, every slot is base +
+// immediate, and consecutive dependence levels of a computation sit in consecutive slots.
 //   slots 0..31   epilogue of the previous tile, one accumulator register (two 128-byte row
-//                 segments) per slot; slot 32: its statistics
-//   slot  TS-1    s_waitcnt vmcnt(0): the DMA of the next tile (issued a whole loop ago) and the
-//                 stores above (a microsecond ago) have landed; first raw read
-//   slots TS+7j.. transform of piece j of the next tile: 4 slots of arithmetic (one channel each),
-//                 split + operand-plane writes, operand-cache store, refill DMA of the piece for
-//                 the tile after next
+//                 segments) per slot, the value formed one slot ahead; slots 32, 33: its statistics
+//   slot  FT-1    counted s_waitcnt: everything up to the refill DMA of the previous loop has landed
+//                 (in order), the 32 (33) stores above may stay in flight; first raw read
+//   slots FT..    transform of the next tile, 18 (12) slots = 3 (2) MFMA steps per piece: arithmetic
+//                 levels, split levels, operand cache, pro_stats, refill DMA of the piece for the tile
+//                 after next.  LDS instructions (raw read of the next piece, operand-plane writes of the
+//                 previous one) sit in slots 0 / 1 of a step only: hipcc waits lgkmcnt(0) in front of
+//                 every step's first MFMA.
 // Tiles at the ends of an utterance (rows outside it: clamped DMA addresses, zeroed operand rows,
-// ownership checks) and partial output tiles take general, masked versions of the same slots.
-
+// ownership checks), partial output tiles and a workgroup's first tile take a plain path.
 // MODE: 0 no transform, 1 affine (per utterance, channel) + x*sigmoid(x), 2 normalisation-backward
 // prologue (nb_*: d y = c1*dz + c2*y + c3 [* (y > 0)] over two input tensors)
 // 3: mode 1 + pro_stats (per-tile sum / sum of squares of the transformed rows the tile owns),
@@ -335,7 +339,7 @@ void sa_conv_ws_kernel(SaConvArgs a, int tiles_per_wg, int total_tiles) {
   auto piece_elem = [&](Tile T, bool edge, int j, int q) {            // channel q of the lane's four
     if (j == WS_DPW - 1 && wave_ + 4 * j >= WS_NDMA) return;
     float v = vx[0][q];
-    if constexpr (SWISH) {                                 // the very operations of piece_stage: a row's operand
+    if constexpr (SWISH) {                                 // the very operations of piece_level: a row's operand
       const float zz = fmaf(v, s1[q], t1[q]);              // must not depend on which path staged it
       v = zz * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(zz * -1.4426950408889634f));
       if constexpr (AFF2) v = fmaf(v, s2[q], t2[q]);
@@ -358,35 +362,55 @@ void sa_conv_ws_kernel(SaConvArgs a, int tiles_per_wg, int total_tiles) {
     if (q == 1) split_pair(f[0], f[1], phi.x, plo.x);
     if (q == 3) split_pair(f[2], f[3], phi.y, plo.y);
   };
-  // The same transform as piece_elem for an interior tile, cut by STAGE instead of by channel: a
-  // slot then holds four independent instructions per stage instead of one six-deep dependent chain
-  // (with one wave per SIMD nothing else covers the latency of a dependent VALU / transcendental op).
+  // The same transform as piece_elem for an interior tile, cut by DEPENDENCE LEVEL instead of by
+  // channel: a slot holds the four independent instructions of one level (one per channel), the
+  // level that consumes them sits in the next slot, 32 cycles later.  With one wave per SIMD nothing
+  // else covers the latency of a dependent VALU or transcendental op: cut by channel pair (two
+  // two-deep chains per slot) the same instructions ran at 42 cycles per MFMA instead of 34.
+  //   arithmetic levels (x*sigmoid(x) modes): 0 z = x*s1 + t1 | 1 w = z * -log2(e) | 2 w = exp2(w) |
+  //   3 w = 1 + w | 4 w = rcp(w) | 5 f = z * w | 6 (second affine) f = f*s2 + t2
+  //   split levels: 0 hi = bf16 pairs | 1 hi as floats | 2 f - hi | 3 lo = bf16 pairs
   float z[4], w[4];
-  auto piece_stage = [&](Tile T, int j, int st, int h) {    // h: channel pair (2h, 2h+1) of the lane's four
+  auto piece_level = [&](Tile T, int j, int lv) {
     if (j == WS_DPW - 1 && wave_ + 4 * j >= WS_NDMA) return;
 #pragma unroll
-    for (int q = 2 * h; q < 2 * h + 2; ++q) {
+    for (int q = 0; q < 4; ++q) {
       if constexpr (MODE == 0) {
-        if (st == 0) f[q] = vx[0][q];
+        if (lv == 0) f[q] = vx[0][q];
       } else if constexpr (MODE == 5) {
-        if (st == 0) f[q] = fmaf(vx[0][q], s2[q], t2[q]);
-      } else if constexpr (SWISH) {                        // x*sigmoid(x), the operations of sa_swish
-        if (st == 0) { z[q] = fmaf(vx[0][q], s1[q], t1[q]); w[q] = z[q] * -1.4426950408889634f; }
-        if (st == 1) w[q] = 1.0f + __builtin_amdgcn_exp2f(w[q]);
-        if (st == 2) {
-          f[q] = z[q] * __builtin_amdgcn_rcpf(w[q]);
-          if constexpr (AFF2) f[q] = fmaf(f[q], s2[q], t2[q]);
-        }
-      } else {
-        if (st == 0) { z[q] = fmaf(k2[q], vy[0][q], k3[q]); f[q] = fmaf(k1[q], vx[0][q], z[q]); }
-        if (st == 1) { if (a.nb_relu_mask) f[q] = vy[0][q] > 0.0f ? f[q] : 0.0f; }
-        if (st == 2) { if (a.nb_colsum && owns(T, false, j)) csum[q] += f[q]; }
+        if (lv == 0) f[q] = fmaf(vx[0][q], s2[q], t2[q]);
+      } else if constexpr (SWISH) {                        // the operations of sa_swish, in its order
+        if (lv == 0) z[q] = fmaf(vx[0][q], s1[q], t1[q]);
+        if (lv == 1) w[q] = z[q] * -1.4426950408889634f;
+        if (lv == 2) w[q] = __builtin_amdgcn_exp2f(w[q]);
+        if (lv == 3) w[q] = 1.0f + w[q];
+        if (lv == 4) w[q] = __builtin_amdgcn_rcpf(w[q]);
+        if (lv == 5) f[q] = z[q] * w[q];
+        if constexpr (AFF2) { if (lv == 6) f[q] = fmaf(f[q], s2[q], t2[q]); }
+      } else {                                             // PRO2 (experiment build)
+        if (lv == 0) z[q] = fmaf(k2[q], vy[0][q], k3[q]);
+        if (lv == 1) f[q] = fmaf(k1[q], vx[0][q], z[q]);
+        if (lv == 2) { if (a.nb_relu_mask) f[q] = vy[0][q] > 0.0f ? f[q] : 0.0f; }
+        if (lv == 3) { if (a.nb_colsum && owns(T, false, j)) csum[q] += f[q]; }
       }
     }
-    if (st == 3) {
-      if (h == 0) split_pair(f[0], f[1], phi.x, plo.x);
-      else split_pair(f[2], f[3], phi.y, plo.y);
+  };
+  auto piece_split = [&](int j, int lv) {
+    if (j == WS_DPW - 1 && wave_ + 4 * j >= WS_NDMA) return;
+    if (lv == 0) {
+      // (opaque: see split_pair -- the split must see the ROUNDED product)
+      asm volatile("" : "+v"(f[0]), "+v"(f[1]), "+v"(f[2]), "+v"(f[3]));
+      phi.x = ws_cvt_pk_bf16(f[0], f[1]); phi.y = ws_cvt_pk_bf16(f[2], f[3]);
     }
+    if (lv == 1) {
+      z[0] = __uint_as_float(phi.x << 16); z[1] = __uint_as_float(phi.x & 0xffff0000u);
+      z[2] = __uint_as_float(phi.y << 16); z[3] = __uint_as_float(phi.y & 0xffff0000u);
+    }
+    if (lv == 2) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) w[q] = f[q] - z[q];
+    }
+    if (lv == 3) { plo.x = ws_cvt_pk_bf16(w[0], w[1]); plo.y = ws_cvt_pk_bf16(w[2], w[3]); }
   };
   auto piece_pstat = [&](Tile T, int j) {                   // pro_stats of an interior tile's piece (slot form)
     if constexpr (PSTAT) {
@@ -578,34 +602,45 @@ void sa_conv_ws_kernel(SaConvArgs a, int tiles_per_wg, int total_tiles) {
       auto filler = [&](auto f_c) {
         constexpr int fs = decltype(f_c)::value;
         if constexpr ((SA_ABL & 8) != 0 || !FAST) return;
-        if constexpr (fs < 64) {
-          if constexpr (fs % 2 == 0) epi_store(fs / 2); else epi_accum(fs / 2);
-        } else if constexpr (fs == 64 || fs == 65) {
-          epi_stats(Tp, fs - 64);
-        } else if constexpr (fs == 66) {
+        if constexpr (fs < 32) {
+          epi_store(fs); epi_accum(fs);
+        } else if constexpr (fs == 32 || fs == 33) {
+          epi_stats(Tp, fs - 32);
+        } else if constexpr (fs == 34) {
           WS_STAMP(it, 3);
         } else if constexpr (fs == WS_FT - 1) {
           WS_STAMP(it, 4);
-          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+          // Everything up to the refill DMA of the previous tile loop has landed: vector-memory
+          // operations complete in order, and behind that DMA this wave has issued exactly the 32
+          // stores (+ 1 statistics store) of the slots above, which may stay in flight.
+          if (has_stats) asm volatile("s_waitcnt vmcnt(33)" ::: "memory");
+          else asm volatile("s_waitcnt vmcnt(32)" ::: "memory");
           WS_STAMP(it, 5);
           piece_read(0);
-        } else if constexpr (fs >= WS_FT && WS_SUBS == 14) {
-          constexpr int j = (fs - WS_FT) / 14, k = (fs - WS_FT) % 14, h = k & 1;
-          if constexpr (k < 8) piece_stage(Tn, j, k / 2, h);
-          if constexpr (j + 1 < WS_DPW && k == 1) piece_read(j + 1, 0);    // stage 0 has consumed the raw piece
-          if constexpr (j + 1 < WS_DPW && k == 3 && PRO2) piece_read(j + 1, 1);
-          if constexpr (k == 8 || k == 9) piece_write(j, h);
-          if constexpr (k == 10) piece_cache(Tn, false, j);
-          if constexpr (k == 11) piece_pstat(Tn, j);
-          if constexpr (k == 12 || (k == 13 && PRO2)) dma_piece(Tnn, false, j, h);
-        } else if constexpr (fs >= WS_FT) {                 // one arithmetic stage: 7 slots per piece
-          constexpr int j = (fs - WS_FT) / 7, k = (fs - WS_FT) % 7;
-          if constexpr (k < 2) piece_stage(Tn, j, 0, k);
+        } else if constexpr (fs >= WS_FT && WS_SUBS == 18) {
+          // 18 slots per piece = three steps: arithmetic levels in slots 0..6, split levels in 8..11,
+          // operand cache, pro_stats, refill DMA behind them; the raw piece is consumed by level 0 (the
+          // next one is read in slot 1) and the operand planes of piece j are written in slots 6 / 7
+          // of piece j+1, i.e. slots 0 / 1 of a step (the last piece's after the loop)
+          constexpr int j = (fs - WS_FT) / 18, k = (fs - WS_FT) % 18;
+          constexpr int NA = AFF2 ? 7 : 6;                  // arithmetic levels of this mode (PRO2: 4, padded)
+          if constexpr (j > 0 && (k == 6 || k == 7)) piece_write(j - 1, k - 6);
+          if constexpr (k < NA) piece_level(Tn, j, k);
           if constexpr (j + 1 < WS_DPW && k == 1) piece_read(j + 1, 0);
-          if constexpr (k == 2 || k == 3) piece_stage(Tn, j, 3, k - 2);
-          if constexpr (k == 4) piece_write(j);
-          if constexpr (k == 5) piece_cache(Tn, false, j);
-          if constexpr (k == 6) dma_piece(Tnn, false, j);
+          if constexpr (j + 1 < WS_DPW && k == 13 && PRO2) piece_read(j + 1, 1);
+          if constexpr (k >= 8 && k < 12) piece_split(j, k - 8);
+          if constexpr (k == 14) piece_cache(Tn, false, j);
+          if constexpr (k == 15) piece_pstat(Tn, j);
+          if constexpr (k == 16) dma_piece(Tnn, false, j, 0);
+          if constexpr (k == 17 && PRO2) dma_piece(Tnn, false, j, 1);
+        } else if constexpr (fs >= WS_FT) {                 // 12 slots per piece = two steps: one arithmetic level
+          constexpr int j = (fs - WS_FT) / 12, k = (fs - WS_FT) % 12;
+          if constexpr (j > 0 && k < 2) piece_write(j - 1, k);                  // (before this piece's split overwrites hi / lo)
+          if constexpr (k == 0) piece_level(Tn, j, 0);
+          if constexpr (j + 1 < WS_DPW && k == 1) piece_read(j + 1, 0);
+          if constexpr (k >= 2 && k < 6) piece_split(j, k - 2);
+          if constexpr (k == 9) piece_cache(Tn, false, j);
+          if constexpr (k == 10) dma_piece(Tnn, false, j);
         }
       };
       load_al(0, 0); load_al(0, 1); load_ah(0, 0); load_ah(0, 1);
@@ -664,6 +699,7 @@ void sa_conv_ws_kernel(SaConvArgs a, int tiles_per_wg, int total_tiles) {
     const bool fast = slotE && slotT && slotD;
     if (fast) {
       tile_body(std::true_type{});
+      piece_write(WS_DPW - 1);                             // (its slots 0 / 1 of a next piece do not exist)
     } else {
       if (doE && !partialE) {                              // (a partial tile had its epilogue above)
 #pragma unroll
