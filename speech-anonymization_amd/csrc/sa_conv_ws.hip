@@ -382,9 +382,9 @@ void sa_conv_ws_kernel(SaConvArgs a, int tiles_per_wg, int total_tiles) {
       } else if constexpr (SWISH) {                        // the operations of sa_swish, in its order
         if (lv == 0) z[q] = fmaf(vx[0][q], s1[q], t1[q]);
         if (lv == 1) w[q] = z[q] * -1.4426950408889634f;
-        if (lv == 2) w[q] = __builtin_amdgcn_exp2f(w[q]);
+        if (lv == 2) w[q] = (SA_ABL & 128) ? w[q] * 0.5f : __builtin_amdgcn_exp2f(w[q]);     // (128: timing-only, no transcendentals)
         if (lv == 3) w[q] = 1.0f + w[q];
-        if (lv == 4) w[q] = __builtin_amdgcn_rcpf(w[q]);
+        if (lv == 4) w[q] = (SA_ABL & 128) ? w[q] * 0.25f : __builtin_amdgcn_rcpf(w[q]);
         if (lv == 5) f[q] = z[q] * w[q];
         if constexpr (AFF2) { if (lv == 6) f[q] = fmaf(f[q], s2[q], t2[q]); }
       } else {                                             // PRO2 (experiment build)
@@ -479,7 +479,7 @@ void sa_conv_ws_kernel(SaConvArgs a, int tiles_per_wg, int total_tiles) {
   auto epi_store = [&](int n) {                             // slot form, full tiles: the store of value n
     const int m = n >> 4, i = n & 15;
     const int ro = m * 32 + (i & 3) + 8 * (i >> 2);         // row in the tile, before the lane half's +4
-    ws_store_b32(ybase_e + ro * (WS_C * 4), y_off, eval);
+    if constexpr ((SA_ABL & 64) == 0) ws_store_b32(ybase_e + ro * (WS_C * 4), y_off, eval);   // (64: timing-only build without the stores)
   };
   auto epi_accum = [&](int n) {                             // ... its statistics, and value n+1 formed
     // (asm: hipcc otherwise sinks all 32 accumulations into the statistics slot, behind its branch)
@@ -559,6 +559,23 @@ void sa_conv_ws_kernel(SaConvArgs a, int tiles_per_wg, int total_tiles) {
   // tile t-1 (from the copied accumulators), the transform of tile t+1 into planes[(it+1) & 1] and
   // the refill DMA of tile t+2.  One barrier per tile.
   for (int t = first, it = 0; t < last; ++t, ++it) {
+    int lanem = lane_;
+    asm volatile("" : "+v"(lanem));
+    const bf16_t* ab = planes + (size_t)(it & 1) * 2 * WS_PLANE + (lanem & 31) * WS_PITCH + (lanem >> 5) * 8;
+    // A fragments of the next step, read behind MFMAs 0 and 1 of this one, i.e. four MFMAs or more
+    // ahead of their use (hipcc waits for all of them once, in front of the next step's MFMA 0): the
+    // lo halves (MFMAs 0, 1) have one slot, refilled behind their last use, the hi halves (2..5) two
+    bf16x8 ah[2][2], al[2];
+    auto a_ptr = [&](int s, int m) {
+      const int tp = s / WS_KSTEPS, k = s % WS_KSTEPS;
+      return ab + toff[tp] + m * 32 * WS_PITCH + k * 16;
+    };
+    auto load_ah = [&](int s, int m) { ah[s & 1][m] = *reinterpret_cast<const bf16x8*>(a_ptr(s, m)); };
+    auto load_al = [&](int s, int m) { al[m] = *reinterpret_cast<const bf16x8*>(a_ptr(s, m) + WS_PLANE); };
+    // the first step's fragments are requested here, behind the barrier: their LDS latency passes
+    // under the scalar set-up of the iteration below
+    load_al(0, 0); load_al(0, 1); load_ah(0, 0); load_ah(0, 1);
+    __builtin_amdgcn_sched_barrier(0);
     const bool doE = t > first, doT = t + 1 < last;
     const Tile Tnn = t + 2 < last ? next_tile(Tn) : Tn;       // (clamped: Tn is already the last tile then)
     const bool edgeT = is_edge(Tn), edgeD = is_edge(Tnn);
@@ -581,19 +598,6 @@ void sa_conv_ws_kernel(SaConvArgs a, int tiles_per_wg, int total_tiles) {
       epi_stats(Tp);
     }
     WS_STAMP(it, 0);
-    int lanem = lane_;
-    asm volatile("" : "+v"(lanem));
-    const bf16_t* ab = planes + (size_t)(it & 1) * 2 * WS_PLANE + (lanem & 31) * WS_PITCH + (lanem >> 5) * 8;
-    // A fragments of the next step, read behind MFMAs 0 and 1 of this one, i.e. four MFMAs or more
-    // ahead of their use (hipcc waits for all of them once, in front of the next step's MFMA 0): the
-    // lo halves (MFMAs 0, 1) have one slot, refilled behind their last use, the hi halves (2..5) two
-    bf16x8 ah[2][2], al[2];
-    auto a_ptr = [&](int s, int m) {
-      const int tp = s / WS_KSTEPS, k = s % WS_KSTEPS;
-      return ab + toff[tp] + m * 32 * WS_PITCH + k * 16;
-    };
-    auto load_ah = [&](int s, int m) { ah[s & 1][m] = *reinterpret_cast<const bf16x8*>(a_ptr(s, m)); };
-    auto load_al = [&](int s, int m) { al[m] = *reinterpret_cast<const bf16x8*>(a_ptr(s, m) + WS_PLANE); };
     // One tile: 240 single-MFMA asm statements with filler slot f behind statement f.  FAST: the
     // steady state (a full previous tile to store, interior tiles to transform and to fetch) with
     // every slot filled, unconditionally; otherwise the bare MFMA loop, the other work around it.
@@ -643,7 +647,6 @@ void sa_conv_ws_kernel(SaConvArgs a, int tiles_per_wg, int total_tiles) {
           if constexpr (k == 10) dma_piece(Tnn, false, j);
         }
       };
-      load_al(0, 0); load_al(0, 1); load_ah(0, 0); load_ah(0, 1);
       // The MFMAs are inline asm so that the weight fragments are AGPR operands where they live
       // (left to itself hipcc parks them in AGPRs and copies each one to VGPRs in front of every
       // use).  The first WS_NAGPR_FRAGS (tap, k-step) pairs take 240 of the 256 AGPRs, the rest stay
