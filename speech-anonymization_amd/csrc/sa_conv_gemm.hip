@@ -587,15 +587,16 @@ extern "C" int sa_conv_gemm_ntiles(int cin, int cout, int u, int Lout) {
 int sa_conv_pp_dispatch(int dtype, int cin, int cout, int sa, int u, const SaConvArgs* a, hipStream_t st);
 int sa_pp_tile_rows(int cin, int cout, int u);
 int sa_pp_share(int cout);
-// Kernel choice.  Default (2): the 128->128 bf16x3 launches the weight-stationary kernel covers
+// Kernel choice.  Default (2): the 128->128 and 64->64 bf16x3 launches the weight-stationary kernel covers
 // (sa_conv_ws.hip: persistent, one wave per SIMD, weights in registers, rows by LDS-DMA, epilogue and
 // transform in the MFMA loop's issue gaps) go there when the launch has at least two tiles per CU --
 // 266 / 289 us against 330 / 367 us (plain / forward with cache + statistics), 190 against 265 us for
-// the 3-tap layers (B = 32, profiles/r02_conv_structure_experiments.md);
+// the 3-tap layers, 190 against 255 us for 64->64 (B = 32, profiles/r02_conv_structure_experiments.md);
 // same slab geometry as this file's 64-row tiles, so nothing else changes for the caller.
 // sa_conv_gemm_set_impl(0): this file's kernel only; (1): the ping-pong kernel for f32 / bf16x3.
 bool sa_conv_ws_covers(int dtype, int cin, int cout, int sa, int u, const SaConvArgs* a);
-int sa_conv_ws_dispatch(const SaConvArgs* a, hipStream_t st);
+int sa_conv_ws_dispatch(int cin, const SaConvArgs* a, hipStream_t st);
+int sa_conv_ws_tile_rows(int cin);
 static int g_use_pp = 0, g_use_ws = 1;
 extern "C" int sa_conv_gemm_set_impl(int impl) {
   if (impl < 0 || impl > 2) return -22;
@@ -666,8 +667,9 @@ extern "C" int sa_abi_sizeof(int which) {
 // which kernel sa_conv_gemm routes this launch to: 0 one-tile, 1 ping-pong, 2 weight-stationary
 static int conv_route(int dtype, int cin, int cout, int sa, int u, const SaConvArgs* a) {
   if (uses_pp(dtype)) return 1;
-  if (g_use_ws && tile_rows(cin, cout, u) == 64 && sa_conv_ws_covers(dtype, cin, cout, sa, u, a) &&
-      (long)a->B * sa_div_up(a->Lout, 64) >= 512)
+  if (g_use_ws && sa_conv_ws_covers(dtype, cin, cout, sa, u, a) &&
+      tile_rows(cin, cout, u) == sa_conv_ws_tile_rows(cin) &&
+      (long)a->B * sa_div_up(a->Lout, sa_conv_ws_tile_rows(cin)) >= 512)
     return 2;
   return 0;
 }
@@ -684,7 +686,7 @@ extern "C" int sa_conv_gemm(int dtype, int cin, int cout, int sa, int u, const S
   if (a->ep_mode < 0 || a->ep_mode > 2 || (a->ep_mode && !a->ep_x)) return -22;
   const int route = conv_route(dtype, cin, cout, sa, u, a);
   if (route == 1) return sa_conv_pp_dispatch(dtype, cin, cout, sa, u, a, st);
-  if (route == 2) return sa_conv_ws_dispatch(a, st);
+  if (route == 2) return sa_conv_ws_dispatch(cin, a, st);
   SA_CONV_CASE(32, 64, 2, 1)
   SA_CONV_CASE(64, 64, 1, 1)
   SA_CONV_CASE(64, 128, 2, 1)

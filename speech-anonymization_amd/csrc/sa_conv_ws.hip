@@ -1,7 +1,8 @@
 // Implicit-GEMM 1-D convolution on MFMA (gfx950), channels-last -- the WEIGHT-STATIONARY form of
-// the 128 -> 128 channel, stride-1 FORWARD launches in the bf16x3 policy (fp32 storage, split-bf16
-// operands): models/ConvAutoEncoder.py:150-158 (encoder.11), :161-166 (decoder.0) and :33-43 (the
-// three TDNN layers of the sex classifier: 5 taps, 3 taps dilation 2, 3 taps dilation 3).
+// the stride-1 FORWARD launches with equal channel counts in the bf16x3 policy (fp32 storage, split-
+// bf16 operands): 128 -> 128, models/ConvAutoEncoder.py:150-158 (encoder.11), :161-166 (decoder.0) and
+// :33-43 (the three TDNN layers of the sex classifier: 5 taps, 3 taps dilation 2, 3 taps dilation 3);
+// 64 -> 64, :146-148 (encoder.5) and :167-169 (decoder.4).
 //
 // Same operation, arguments, statistics-slab geometry and output BITS as the 64-row one-tile kernel
 // (sa_conv_gemm.hip); different execution structure, chosen from the measurements in
@@ -9,7 +10,8 @@
 // 76 us + weight-fragment stream 61 us + MFMA 122 us + epilogue 37 us + launch floor 45 us):
 //
 //   * ONE persistent 4-wave workgroup per CU (one wave per SIMD, the whole 512-register file per
-//     lane); a workgroup walks a contiguous range of 64-row tiles.
+//     lane); a workgroup walks a contiguous range of 64-row tiles (64 channels: 128-row tiles, the
+//     waves being two column blocks x two row halves).
 //   * The weights never move: wave w owns output columns [32w, 32w+32) and keeps its B fragments
 //     for all taps x 128 input channels x (hi, lo) -- 80 fragments = 320 registers with 5 taps -- for
 //     the whole launch (the one-tile kernel re-streams 327 KB of fragments from L2 per tile); 256 of
@@ -61,31 +63,35 @@ extern "C" int sa_ws_dbg_read(unsigned long long* out) {
 
 namespace {
 
-constexpr int WS_C = 128;                  // channels in = channels out
-constexpr int WS_TM = 64;                  // output rows per tile
-constexpr int WS_KSTEPS = WS_C / 16;
-constexpr int WS_PITCH = WS_C + 8;         // bf16 elements per LDS operand row (272 B: conflict-free ds_read_b128)
-
-// geometry of one instantiation: NT taps spanning HALO rows (5 taps at unit spacing: 4; the dilated
-// 3-tap TDNN layers: 4 and 6)
-template <int NT, int HALO_>
+// geometry of one instantiation: C_ channels in and out (128 or 64), NT taps spanning HALO rows (5 taps
+// at unit spacing: 4; the dilated 3-tap TDNN layers: 4 and 6).  A wave always owns 64 rows x 32 columns
+// (two 32x32 accumulators, six MFMAs per k-step): with 128 channels the four waves are four column
+// blocks of a 64-row tile, with 64 channels two column blocks x two row halves of a 128-row tile.
+template <int C_, int NT, int HALO_>
 struct WsGeo {
-  static constexpr int NTAPS = NT, HALO = HALO_;
-  static constexpr int ROWS = WS_TM + HALO_;               // staged input rows per tile
-  static constexpr int PLANE = ROWS * WS_PITCH;            // bf16 elements per plane
-  static constexpr int NDMA = ROWS / 2;                    // 1-KiB DMA pieces (2 rows each) per tile and tensor
+  static constexpr int C = C_, NTAPS = NT, HALO = HALO_;
+  static constexpr int NWN = C_ / 32, NWM = 4 / NWN;       // waves along the columns / the rows
+  static constexpr int TM = 64 * NWM;                      // output rows per tile
+  static constexpr int KSTEPS = C_ / 16;
+  static constexpr int PITCH = C_ + 8;                     // bf16 elements per LDS operand row (conflict-free ds_read_b128)
+  static constexpr int RPP = 256 / C_;                     // rows per 1-KiB DMA piece (2 or 4)
+  static constexpr int LPR = 64 / RPP;                     // lanes per row of a piece (4 channels each)
+  static constexpr int ROWS = TM + HALO_;                  // staged input rows per tile
+  static_assert(ROWS % RPP == 0, "whole DMA pieces");
+  static constexpr int PLANE = ROWS * PITCH;               // bf16 elements per plane
+  static constexpr int NDMA = ROWS / RPP;                  // 1-KiB DMA pieces per tile and tensor
   static constexpr int DPW = (NDMA + 3) / 4;               // pieces per wave (the last waves have one less)
-  static constexpr int RAW_BYTES = ROWS * WS_C * 4;        // one raw fp32 tile
+  static constexpr int RAW_BYTES = ROWS * C_ * 4;          // one raw fp32 tile
   static constexpr int BUF_BYTES = 2 * PLANE * 2;          // one operand buffer (hi + lo planes)
   // (tap, k-step) pairs whose hi + lo weight fragments live in AGPRs (at most all 256 of them)
-  static constexpr int NAGPR_FRAGS = NT * WS_KSTEPS < 32 ? NT * WS_KSTEPS : 32;
-  static constexpr int NSLOT = NT * WS_KSTEPS * 6;         // MFMAs = filler slots per tile
+  static constexpr int NAGPR_FRAGS = NT * KSTEPS < 32 ? NT * KSTEPS : 32;
+  static constexpr int NSLOT = NT * KSTEPS * 6;            // MFMAs = filler slots per tile
   // slots per piece of the transform: 18 where the tile has 240 slots (up to seven arithmetic
   // levels), 12 (one level) for the 3-tap layers' 144.  Multiples of a step's six slots: the LDS
   // instructions of a piece (raw read, operand-plane writes) then always sit in slots 0 / 1 of a step,
   // four MFMAs ahead of the lgkmcnt(0) that hipcc puts in front of the next step's first MFMA.  The
   // epilogue takes slots 0..33 (one accumulator register per slot, then the statistics).
-  static constexpr int SUBS = NT == 5 ? 18 : 12;
+  static constexpr int SUBS = C_ == 64 ? 6 : NT == 5 ? 18 : 12;   // (64 channels: 120 slots per tile, levels in pairs)
   static constexpr int FT = NSLOT - SUBS * DPW;            // first transform slot
   static_assert(FT > 34 && FT % 6 == 0, "epilogue slots / step alignment");
 };
@@ -154,10 +160,13 @@ __device__ __forceinline__ void ws_static_for(F&& f) {
 // 3: mode 1 + pro_stats (per-tile sum / sum of squares of the transformed rows the tile owns),
 // 4: mode 1 + a second, per-channel affine (the classifier's input BatchNorm behind the activation)
 // 5: one per-channel affine only (the dilated TDNN layers: BatchNorm of the layer below in front)
-template <int MODE, int NT, int HALO>
+template <int MODE, int NT, int HALO, int CC = 128>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1)))
 void sa_conv_ws_kernel(SaConvArgs a, int tiles_per_wg, int total_tiles) {
-  typedef WsGeo<NT, HALO> G;
+  typedef WsGeo<CC, NT, HALO> G;
+  constexpr int WS_C = G::C, WS_TM = G::TM, WS_KSTEPS = G::KSTEPS, WS_PITCH = G::PITCH, RPP = G::RPP, LPR = G::LPR,
+                NWN = G::NWN, NWM = G::NWM;
+  static_assert(CC == 128 || MODE == 0 || MODE == 1, "64 channels: plain and affine + x*sigmoid(x) prologues");
   constexpr int WS_NTAPS = G::NTAPS, WS_ROWS = G::ROWS, WS_PLANE = G::PLANE, WS_NDMA = G::NDMA, WS_DPW = G::DPW,
                 WS_RAW_BYTES = G::RAW_BYTES, WS_BUF_BYTES = G::BUF_BYTES, WS_NAGPR_FRAGS = G::NAGPR_FRAGS,
                 WS_FT = G::FT, WS_SUBS = G::SUBS;
@@ -174,6 +183,7 @@ void sa_conv_ws_kernel(SaConvArgs a, int tiles_per_wg, int total_tiles) {
   const unsigned raw_lds = (unsigned)(uintptr_t)(lds_byte*)raw;
   const int tid = threadIdx.x, lane_ = tid & 63;
   const int wave_ = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wn_ = wave_ % NWN, wm_ = wave_ / NWN;           // this wave's column block / row half of the tile
   const int first = blockIdx.x * tiles_per_wg;
   int last = first + tiles_per_wg;
   if (last > total_tiles) last = total_tiles;
@@ -185,11 +195,11 @@ void sa_conv_ws_kernel(SaConvArgs a, int tiles_per_wg, int total_tiles) {
     const bf16x8* wp = reinterpret_cast<const bf16x8*>(a.wp);
 #pragma unroll
     for (int t = 0; t < WS_NTAPS; ++t) {
-      const bf16x8* wt = wp + ((size_t)a.taps.widx[0][t] * WS_KSTEPS * 4 + wave_) * 64 + lane_;
+      const bf16x8* wt = wp + ((size_t)a.taps.widx[0][t] * WS_KSTEPS * NWN + wn_) * 64 + lane_;
 #pragma unroll
       for (int k = 0; k < WS_KSTEPS; ++k) {
-        Bh[t][k] = wt[(size_t)k * 4 * 64];
-        Bl[t][k] = wt[(size_t)a.wlo_off + (size_t)k * 4 * 64];
+        Bh[t][k] = wt[(size_t)k * NWN * 64];
+        Bl[t][k] = wt[(size_t)a.wlo_off + (size_t)k * NWN * 64];
       }
       // one tap at a time, moved to its AGPR home before the next tap is fetched (all 80 loads at
       // once would need 320 VGPRs).  The empty asm also makes hipcc wait for the loads HERE: a value
@@ -203,21 +213,22 @@ void sa_conv_ws_kernel(SaConvArgs a, int tiles_per_wg, int total_tiles) {
       __builtin_amdgcn_sched_barrier(0);
     }
   }
-  float bv = a.bias ? a.bias[wave_ * 32 + (lane_ & 31)] : 0.0f;
+  float bv = a.bias ? a.bias[wn_ * 32 + (lane_ & 31)] : 0.0f;
   float relu_floor = a.relu ? 0.0f : -__builtin_inff();     // max(v, -inf) = v: no branch in the slot
   const bool has_stats = a.stats != nullptr, has_ao = a.a_out != nullptr;
 
   // ---- lane constants of the filler slots (made opaque so that hipcc keeps THESE and derives the
   // per-slot addresses from them by immediates, instead of hoisting one address chain per slot) ----
-  const int half_ = lane_ >> 5, l31_ = lane_ & 31;             // row of the piece's two, channel quad
-  // this wave's piece j is piece i = wave + 4j of the tile: rows 2i + half, i.e. row (2 wave + half) + 8j
-  unsigned row0 = 2 * wave_ + half_;
-  unsigned dma_off = row0 * (WS_C * 4) + l31_ * 16;        // byte offset in the row block of a tile (x, nb_x): + j*4096
+  const int half_ = lane_ >> 5, l31_ = lane_ & 31;             // accumulator layout: rows +4, column
+  const int rowp_ = lane_ / LPR, cq_ = lane_ % LPR;            // transform layout: row of the piece, channel quad
+  // this wave's piece j is piece i = wave + 4j of the tile: rows RPP*i + rowp, i.e. row0 + 4*RPP*j
+  unsigned row0 = RPP * wave_ + rowp_;
+  unsigned dma_off = wave_ * 1024 + lane_ * 16;            // byte offset in the row block of a tile (rows are contiguous): + j*4096
   unsigned raw_off = wave_ * 1024 + lane_ * 16;            // byte offset in the raw tile: + j*4096
-  unsigned pl_off = (row0 * WS_PITCH + l31_ * 4) * 2;      // byte offset in an operand plane: + j*8*PITCH*2
-  unsigned ao_off = (row0 * WS_C + l31_ * 4) * 2;          // byte offset in the a_out row block: + j*8*C*2
-  unsigned y_off = (4 * half_ * WS_C + wave_ * 32 + l31_) * 4;   // byte offset in the y row block: + ro*512
-  unsigned st_off = (wave_ * 32 + l31_) * 8;               // byte offset of this lane's column in a statistics slab
+  unsigned pl_off = (row0 * WS_PITCH + cq_ * 4) * 2;       // byte offset in an operand plane: + j*4*RPP*PITCH*2
+  unsigned ao_off = (row0 * WS_C + cq_ * 4) * 2;           // byte offset in the a_out row block: + j*4*RPP*C*2
+  unsigned y_off = ((4 * half_ + 64 * wm_) * WS_C + wn_ * 32 + l31_) * 4;   // byte offset in the y row block: + ro*C*4
+  unsigned st_off = (wn_ * 32 + l31_) * 8;                 // byte offset of this lane's column in a statistics slab
   unsigned swap_off = (lane_ ^ 32) * 4;                    // ds_bpermute address of the lane in the other half
   asm volatile("" : "+v"(bv), "+v"(relu_floor), "+v"(row0), "+v"(dma_off), "+v"(raw_off), "+v"(pl_off), "+v"(ao_off), "+v"(y_off),
                "+v"(st_off), "+v"(swap_off));
@@ -240,14 +251,14 @@ void sa_conv_ws_kernel(SaConvArgs a, int tiles_per_wg, int total_tiles) {
   if constexpr (AFF2) {                                     // per channel: loaded once
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-      s2[j] = a.s2[(lane_ & 31) * 4 + j];
-      t2[j] = a.t2 ? a.t2[(lane_ & 31) * 4 + j] : 0.0f;
+      s2[j] = a.s2[cq_ * 4 + j];
+      t2[j] = a.t2 ? a.t2[cq_ * 4 + j] : 0.0f;
       asm volatile("" : "+v"(s2[j]), "+v"(t2[j]));
     }
   }
   auto load_consts = [&](int b) {
     WS_IDS;
-    const int ch = (lane & 31) * 4;
+    const int ch = (lane % LPR) * 4;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       if constexpr (SWISH) {
@@ -289,9 +300,9 @@ void sa_conv_ws_kernel(SaConvArgs a, int tiles_per_wg, int total_tiles) {
       }
     } else {
       WS_IDS;
-      int g = g0 + 2 * i + (lane >> 5);
+      int g = g0 + RPP * i + lane / LPR;
       g = g < 0 ? 0 : (g >= a.Lin ? a.Lin - 1 : g);        // rows outside the utterance: any valid address (zeroed in the transform)
-      const size_t off = ((size_t)T.b * a.Lin + g) * (WS_C * 4) + (lane & 31) * 16;
+      const size_t off = ((size_t)T.b * a.Lin + g) * (WS_C * 4) + (lane % LPR) * 16;
       ws_dma16(reinterpret_cast<const char*>(a.x) + off, raw_lds + i * 1024);
       if constexpr (PRO2) ws_dma16(reinterpret_cast<const char*>(a.nb_x) + off, raw_lds + WS_RAW_BYTES + i * 1024);
     }
@@ -317,14 +328,14 @@ void sa_conv_ws_kernel(SaConvArgs a, int tiles_per_wg, int total_tiles) {
   // is this lane's row of piece j one the tile owns (operand cache, column sums)?  interior tiles:
   // every piece but the two halo pieces (i = 0: rows -2, -1; i = 33: rows 64, 65), a wave-uniform test
   auto owns = [&](Tile T, bool edge, int j) -> bool {
-    if (!edge) {                                           // own rows = staged rows [-rowmin, -rowmin + 64): whole pieces
-      const int i = wave_ + 4 * j, lo = -a.rowmin >> 1;    // (rowmin is even: checked at launch)
-      if (j > 0 && j < WS_DPW - 2) return true;            // pieces 4..27 are owned in every geometry
-      return i >= lo && i < lo + WS_TM / 2;
+    if (!edge) {                                           // own rows = staged rows [-rowmin, -rowmin + TM)
+      if (j > 0 && j < WS_DPW - 2) return true;            // the middle pieces are owned in every geometry
+      const int r = (int)row0 + 4 * RPP * j;               // (per lane where a piece straddles the boundary)
+      return r >= -a.rowmin && r < -a.rowmin + WS_TM;
     }
     int lo, hi;
     own_range(T, lo, hi);
-    const int g = T.tile * WS_TM + a.rowmin + (int)row0 + 8 * j;
+    const int g = T.tile * WS_TM + a.rowmin + (int)row0 + 4 * RPP * j;
     return g >= lo && g < hi;
   };
   // hi = bf16(v), lo = bf16(v - hi) of a channel pair (same roundings as sa_split4)
@@ -355,7 +366,7 @@ void sa_conv_ws_kernel(SaConvArgs a, int tiles_per_wg, int total_tiles) {
       if (a.nb_colsum && owns(T, edge, j)) csum[q] += v;
     }
     if (edge) {                                            // rows outside the utterance are zero operands
-      const int g = T.tile * WS_TM + a.rowmin + (int)row0 + 8 * j;
+      const int g = T.tile * WS_TM + a.rowmin + (int)row0 + 4 * RPP * j;
       if (!(g >= 0 && g < a.Lin)) v = 0.0f;
     }
     f[q] = v;
@@ -423,13 +434,13 @@ void sa_conv_ws_kernel(SaConvArgs a, int tiles_per_wg, int total_tiles) {
   };
   auto piece_write = [&](int j, int part = 2) {             // operand planes of the transform tile (0 hi, 1 lo, 2 both)
     if (j == WS_DPW - 1 && wave_ + 4 * j >= WS_NDMA) return;
-    unsigned char* dst = smem + (pl_cur + j * (8 * WS_PITCH * 2));
+    unsigned char* dst = smem + (pl_cur + j * (4 * RPP * WS_PITCH * 2));
     if (part != 1) *reinterpret_cast<uint2*>(dst) = phi;
     if (part != 0) *reinterpret_cast<uint2*>(dst + WS_PLANE * 2) = plo;
   };
   auto piece_cache = [&](Tile T, bool edge, int j) {          // bf16 operand cache for sa_wgrad: hi values of the owned rows
     if (j == WS_DPW - 1 && wave_ + 4 * j >= WS_NDMA) return;
-    if (has_ao && owns(T, edge, j)) ws_store_b64(aobase_t + j * (8 * WS_C * 2), ao_off, phi);
+    if (has_ao && owns(T, edge, j)) ws_store_b64(aobase_t + j * (4 * RPP * WS_C * 2), ao_off, phi);
   };
   // per-tile column reductions of the transform (PRO2: column sums of d y; pro_stats: sum and sum of
   // squares of the transformed rows): fold the two row halves of the wave, one LDS slot per wave,
@@ -495,7 +506,7 @@ void sa_conv_ws_kernel(SaConvArgs a, int tiles_per_wg, int total_tiles) {
       const int m = n >> 4, i = n & 15;
       const int ro = m * 32 + (i & 3) + 8 * (i >> 2);
       const float val = epi_form(n);
-      if (T.tile * WS_TM + ro + 4 * (lane >> 5) < a.Lout) {
+      if (T.tile * WS_TM + 64 * wm_ + ro + 4 * (lane >> 5) < a.Lout) {
         *reinterpret_cast<float*>(ybase_e + ro * (WS_C * 4) + y_off) = val;
         ssum += val; ssq = fmaf(val, val, ssq);
       }
@@ -504,6 +515,8 @@ void sa_conv_ws_kernel(SaConvArgs a, int tiles_per_wg, int total_tiles) {
   // statistics of a tile: fold the two lane halves (a lane owns one column, the other half holds the
   // rows +4) and store; both halves then hold the same sums and write the same slab entry
   float st_s = 0.0f, st_q = 0.0f;
+  bool st_pending = false;                                  // (64 channels) partial sums wait in LDS for the tile barrier
+  int st_it = 0;
   char* stbase_e = nullptr;                                 // statistics slab of the epilogue tile
   auto epi_stats = [&](Tile T, int part = 2) {              // 0: fold the lane halves, 1: store, 2: both
     if (has_stats) {
@@ -511,9 +524,29 @@ void sa_conv_ws_kernel(SaConvArgs a, int tiles_per_wg, int total_tiles) {
         st_s = ssum + __int_as_float(__builtin_amdgcn_ds_bpermute((int)swap_off, __float_as_int(ssum)));
         st_q = ssq + __int_as_float(__builtin_amdgcn_ds_bpermute((int)swap_off, __float_as_int(ssq)));
       }
-      if (part != 0) ws_store_b64(stbase_e, st_off, make_uint2(__float_as_uint(st_s), __float_as_uint(st_q)));
+      if (part != 0) {
+        if constexpr (NWM == 1) {
+          ws_store_b64(stbase_e, st_off, make_uint2(__float_as_uint(st_s), __float_as_uint(st_q)));
+        } else {                                           // two row halves share a column: summed after the tile barrier
+          float2* stred = reinterpret_cast<float2*>(raw + WS_RAW_BYTES) + (size_t)(st_it & 1) * 4 * 32;
+          if (lane_ < 32) stred[wave_ * 32 + lane_] = make_float2(st_s, st_q);
+          st_pending = true;
+        }
+      }
     }
     if (part != 0) { ssum = 0.0f; ssq = 0.0f; }
+  };
+  // (64 channels) after the barrier that follows epi_stats: the waves of row half 0 add the two halves
+  auto stats_out = [&]() {
+    if constexpr (NWM == 2) {
+      if (st_pending && wm_ == 0) {
+        const float2* stred = reinterpret_cast<const float2*>(raw + WS_RAW_BYTES) + (size_t)(st_it & 1) * 4 * 32;
+        const float2 p0 = stred[wave_ * 32 + (lane_ & 31)], p1 = stred[(wave_ + NWN) * 32 + (lane_ & 31)];
+        ws_store_b64(stbase_e, st_off, make_uint2(__float_as_uint(p0.x + p1.x), __float_as_uint(p0.y + p1.y)));
+      }
+      st_pending = false;
+      ++st_it;
+    }
   };
 
   int toff[WS_NTAPS];
@@ -561,7 +594,7 @@ void sa_conv_ws_kernel(SaConvArgs a, int tiles_per_wg, int total_tiles) {
   for (int t = first, it = 0; t < last; ++t, ++it) {
     int lanem = lane_;
     asm volatile("" : "+v"(lanem));
-    const bf16_t* ab = planes + (size_t)(it & 1) * 2 * WS_PLANE + (lanem & 31) * WS_PITCH + (lanem >> 5) * 8;
+    const bf16_t* ab = planes + (size_t)(it & 1) * 2 * WS_PLANE + ((lanem & 31) + 64 * wm_) * WS_PITCH + (lanem >> 5) * 8;
     // A fragments of the next step, read behind MFMAs 0 and 1 of this one, i.e. four MFMAs or more
     // ahead of their use (hipcc waits for all of them once, in front of the next step's MFMA 0): the
     // lo halves (MFMAs 0, 1) have one slot, refilled behind their last use, the hi halves (2..5) two
@@ -617,8 +650,8 @@ void sa_conv_ws_kernel(SaConvArgs a, int tiles_per_wg, int total_tiles) {
           // Everything up to the refill DMA of the previous tile loop has landed: vector-memory
           // operations complete in order, and behind that DMA this wave has issued exactly the 32
           // stores (+ 1 statistics store) of the slots above, which may stay in flight.
-          if (has_stats) asm volatile("s_waitcnt vmcnt(33)" ::: "memory");
-          else asm volatile("s_waitcnt vmcnt(32)" ::: "memory");
+          if (NWM == 1 && has_stats) asm volatile("s_waitcnt vmcnt(33)" ::: "memory");
+          else asm volatile("s_waitcnt vmcnt(32)" ::: "memory");      // (64 channels: the statistics are stored behind the barrier)
           WS_STAMP(it, 5);
           piece_read(0);
         } else if constexpr (fs >= WS_FT && WS_SUBS == 18) {
@@ -637,6 +670,18 @@ void sa_conv_ws_kernel(SaConvArgs a, int tiles_per_wg, int total_tiles) {
           if constexpr (k == 15) piece_pstat(Tn, j);
           if constexpr (k == 16) dma_piece(Tnn, false, j, 0);
           if constexpr (k == 17 && PRO2) dma_piece(Tnn, false, j, 1);
+        } else if constexpr (fs >= WS_FT && WS_SUBS == 6) {
+          // 64 channels: a tile has 120 slots for the same transform work: 6 slots per piece = one
+          // step, two dependence levels per slot (over-full on purpose: these launches are HBM-bound)
+          constexpr int j = (fs - WS_FT) / 6, k = (fs - WS_FT) % 6;
+          if constexpr (j > 0 && k < 2) piece_write(j - 1, k);
+          if constexpr (k == 0) { piece_level(Tn, j, 0); piece_level(Tn, j, 1); }
+          if constexpr (j + 1 < WS_DPW && k == 1) piece_read(j + 1, 0);
+          if constexpr (k == 1) { piece_level(Tn, j, 2); piece_level(Tn, j, 3); }
+          if constexpr (k == 2) { piece_level(Tn, j, 4); piece_level(Tn, j, 5); }
+          if constexpr (k == 3) { piece_split(j, 0); piece_split(j, 1); }
+          if constexpr (k == 4) { piece_split(j, 2); piece_split(j, 3); }
+          if constexpr (k == 5) { piece_cache(Tn, false, j); dma_piece(Tnn, false, j); }
         } else if constexpr (fs >= WS_FT) {                 // 12 slots per piece = two steps: one arithmetic level
           constexpr int j = (fs - WS_FT) / 12, k = (fs - WS_FT) % 12;
           if constexpr (j > 0 && k < 2) piece_write(j - 1, k);                  // (before this piece's split overwrites hi / lo)
@@ -745,6 +790,7 @@ void sa_conv_ws_kernel(SaConvArgs a, int tiles_per_wg, int total_tiles) {
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();                          // planes[(it+1) & 1] complete; planes[it & 1] free
     WS_STAMP(it, 2);
+    stats_out();
     if (doT) colsum_out(t + 1, it + 1);
     Tp = Tc; Tc = Tn; Tn = Tnn;
   }
@@ -757,14 +803,20 @@ void sa_conv_ws_kernel(SaConvArgs a, int tiles_per_wg, int total_tiles) {
 #pragma unroll
     for (int n = 0; n < 32; ++n) epi_value(Tp, partialE, n);
     epi_stats(Tp);
+    if constexpr (NWM == 2) {
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      stats_out();
+    }
   }
 #undef WS_IDS
 }
 
-template <int MODE, int NT = 5, int HALO = 4>
+template <int MODE, int NT = 5, int HALO = 4, int CC = 128>
 int launch_ws(const SaConvArgs& a, hipStream_t st) {
-  typedef WsGeo<NT, HALO> G;
-  constexpr int WS_NTAPS = G::NTAPS, WS_HALO = G::HALO, WS_ROWS = G::ROWS, WS_RAW_BYTES = G::RAW_BYTES, WS_BUF_BYTES = G::BUF_BYTES;
+  typedef WsGeo<CC, NT, HALO> G;
+  constexpr int WS_NTAPS = G::NTAPS, WS_HALO = G::HALO, WS_ROWS = G::ROWS, WS_RAW_BYTES = G::RAW_BYTES, WS_BUF_BYTES = G::BUF_BYTES,
+                WS_C = G::C, WS_TM = G::TM, WS_KSTEPS = G::KSTEPS;
   SaConvArgs args = a;
   args.ntiles = sa_div_up(a.Lout, WS_TM);
   int omin = 1 << 30, omax = -(1 << 30), wmax = 0;
@@ -776,13 +828,14 @@ int launch_ws(const SaConvArgs& a, hipStream_t st) {
   if (omax - omin != WS_HALO) return -22;
   args.rowmin = omin;
   args.nrows = WS_ROWS;
-  args.wlo_off = (wmax + 1) * WS_KSTEPS * 4 * 64;        // fragment units: size of the hi image
+  args.wlo_off = (wmax + 1) * WS_KSTEPS * G::NWN * 64;   // fragment units: size of the hi image
   if ((a.a_out || a.nb_colsum || a.pro_stats) &&
       (omin > 0 || omax < 0 || (args.ntiles - 1) * WS_TM + omin + WS_ROWS < a.Lin))
     return -22;                                           // every input row must be staged by the tile that owns it
   if ((long)a.B * a.Lin >= (1L << 31) - 64 || (long)a.B * a.Lout >= (1L << 31) - 64) return -22;   // 32-bit row indices in the kernel
-  const size_t lds = 2 * WS_BUF_BYTES + (MODE == 2 ? 2 : 1) * WS_RAW_BYTES + (MODE == 2 ? 2 * 4 * WS_C * 4 : MODE == 3 ? 2 * 4 * WS_C * 8 : 0);
-  auto kern = sa_conv_ws_kernel<MODE, NT, HALO>;
+  const size_t lds = 2 * WS_BUF_BYTES + (MODE == 2 ? 2 : 1) * WS_RAW_BYTES +
+                     (MODE == 2 ? 2 * 4 * WS_C * 4 : MODE == 3 ? 2 * 4 * WS_C * 8 : G::NWM == 2 ? 2 * 4 * 32 * 8 : 0);
+  auto kern = sa_conv_ws_kernel<MODE, NT, HALO, CC>;
   static bool attr_set = false;
   static int n_cu = 0;
   if (!attr_set) {
@@ -807,8 +860,9 @@ int launch_ws(const SaConvArgs& a, hipStream_t st) {
 
 // Does the weight-stationary kernel serve this launch?  (sa_conv_gemm.hip asks before routing.)
 bool sa_conv_ws_covers(int dtype, int cin, int cout, int sa, int u, const SaConvArgs* a) {
-  if (dtype != SA_BF16X3 || cin != WS_C || cout != WS_C || sa != 1 || u != 1) return false;
+  if (dtype != SA_BF16X3 || cin != cout || (cin != 128 && cin != 64) || sa != 1 || u != 1) return false;
   const int nt = a->taps.ntaps[0];
+  if (cin == 64 && (nt != 5 || a->s2 || a->t2 || a->pro_stats || a->nb_x)) return false;   // 64 channels: the forward layers' two forms
   if ((nt != 5 && nt != 3) || a->wscale) return false;
   if (a->ep_mode) return false;
   int omin = 1 << 30, omax = -(1 << 30);
@@ -821,7 +875,7 @@ bool sa_conv_ws_covers(int dtype, int cin, int cout, int sa, int u, const SaConv
   // the slots' ownership test (operand cache, column sums, pro_stats) works on whole DMA pieces (row
   // pairs): the tile's own rows must start at an even staged row
   if ((a->a_out || a->nb_colsum || a->pro_stats) && (omin > 0 || (omin & 1))) return false;
-  if (a->tile_rows && a->tile_rows != WS_TM) return false;
+  if (a->tile_rows && a->tile_rows != (cin == 64 ? 128 : 64)) return false;
 #ifndef SA_WS_PRO2
   if (a->nb_x) return false;                              // data gradients stay on the one-tile kernel (header)
 #else
@@ -835,7 +889,11 @@ bool sa_conv_ws_covers(int dtype, int cin, int cout, int sa, int u, const SaConv
   return !a->swish;
 }
 
-int sa_conv_ws_dispatch(const SaConvArgs* a, hipStream_t st) {
+// output rows per tile (the one-tile kernel must be on the same tile height: same slab geometry)
+int sa_conv_ws_tile_rows(int cin) { return cin == 64 ? 128 : 64; }
+
+int sa_conv_ws_dispatch(int cin, const SaConvArgs* a, hipStream_t st) {
+  if (cin == 64) return a->s1 ? launch_ws<1, 5, 4, 64>(*a, st) : launch_ws<0, 5, 4, 64>(*a, st);
   if (a->taps.ntaps[0] == 3) {
     int omin = 1 << 30, omax = -(1 << 30);
     for (int t = 0; t < 3; ++t) {

@@ -168,7 +168,7 @@ def _conv_geometry(code, cin, cout, u, Lout):
 
 def conv_impl(pingpong=False, tile_rows=0, pp_rows=0, ws=True):
     """kernel choice for the f32 / bf16x3 policies (A/B timing, kernel tests).  Default: the
-    weight-stationary kernel (sa_conv_ws.hip) for the large 128->128 bf16x3 launches it covers, the
+    weight-stationary kernel (sa_conv_ws.hip) for the large 128->128 / 64->64 bf16x3 launches it covers, the
     one-tile-per-workgroup kernel for everything else; ws=False: one-tile kernel only; pingpong=True:
     the two-groups-in-anti-phase kernel (sa_conv_pp.hip).  Tile-row knobs of the latter two (0 = policy)."""
     lib = L.load()
