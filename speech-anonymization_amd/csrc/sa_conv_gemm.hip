@@ -589,7 +589,8 @@ int sa_pp_tile_rows(int cin, int cout, int u);
 int sa_pp_share(int cout);
 // Kernel choice.  Default (2): the 128->128 and 64->64 bf16x3 launches the weight-stationary kernel covers
 // (sa_conv_ws.hip: persistent, one wave per SIMD, weights in registers, rows by LDS-DMA, epilogue and
-// transform in the MFMA loop's issue gaps) go there when the launch has at least two tiles per CU --
+// transform in the MFMA loop's issue gaps) go there when the launch has at least six tiles per CU (below that the un-overlapped first tiles of
+// every workgroup cost more than the rest gains: B = 4 at the training length loses, B = 6 wins) --
 // 266 / 289 us against 330 / 367 us (plain / forward with cache + statistics), 190 against 265 us for
 // the 3-tap layers, 190 against 255 us for 64->64 (B = 32, profiles/r02_conv_structure_experiments.md);
 // same slab geometry as this file's 64-row tiles, so nothing else changes for the caller.
@@ -669,7 +670,7 @@ static int conv_route(int dtype, int cin, int cout, int sa, int u, const SaConvA
   if (uses_pp(dtype)) return 1;
   if (g_use_ws && sa_conv_ws_covers(dtype, cin, cout, sa, u, a) &&
       tile_rows(cin, cout, u) == sa_conv_ws_tile_rows(cin) &&
-      (long)a->B * sa_div_up(a->Lout, sa_conv_ws_tile_rows(cin)) >= 512)
+      (long)a->B * sa_div_up(a->Lout, sa_conv_ws_tile_rows(cin)) >= 1536)
     return 2;
   return 0;
 }

@@ -667,7 +667,7 @@ def test_weight_stationary_conv_kernel(mode, Ln, pad):
     of the in-tile sums, and both against the fp32 torch convolution.  `ragged`: a partial last tile;
     `valid`: no padding, Lout = Lin - 4 (the trailing input rows belong to the last tile)."""
     from speech_anonymization_amd import _lib as L, ops
-    d, B = dev(), 4
+    d, B = dev(), 6
     g = torch.Generator().manual_seed(11)
     x = torch.randn(B, Ln, 128, generator=g).to(d)
     w = (torch.randn(128, 128, 5, generator=g) * 0.05).to(d)
@@ -699,6 +699,11 @@ def test_weight_stationary_conv_kernel(mode, Ln, pad):
 
     try:
         ref, got = run(False), run(True)
+        import ctypes as C
+        a = L.SaConvArgs()                                           # (the comparison is not one-tile against one-tile)
+        a.B, a.Lin, a.Lout = B, Ln, Lout
+        a.taps = L.make_taps(ops.taps_conv(5, 1, pad))
+        assert L.load().sa_conv_gemm_route(L.BF16X3, 128, 128, 1, 1, C.byref(a)) == 2
     finally:
         ops.conv_impl()
     assert torch.equal(ref[0], got[0])                               # y: bit-equal
@@ -728,7 +733,7 @@ def test_weight_stationary_conv_kernel_dilated(dil, affine):
     the weight-stationary kernel: 144 MFMAs per tile, the per-channel BatchNorm affine of the layer
     below as prologue, ReLU + statistics + operand cache; output bits == the one-tile kernel"""
     from speech_anonymization_amd import _lib as L, ops
-    d, B, Ln = dev(), 4, 20156
+    d, B, Ln = dev(), 6, 20156
     g = torch.Generator().manual_seed(13 + dil)
     x = torch.randn(B, Ln, 128, generator=g).to(d)
     w = (torch.randn(128, 128, 3, generator=g) * 0.05).to(d)
@@ -749,7 +754,11 @@ def test_weight_stationary_conv_kernel_dilated(dil, affine):
 
     try:
         ref, got = run(False), run(True)
+        import ctypes as C
         a = L.SaConvArgs()
+        a.B, a.Lin, a.Lout = B, Ln, Lout
+        a.taps = L.make_taps(ops.taps_conv(3, dil, 0))
+        assert L.load().sa_conv_gemm_route(L.BF16X3, 128, 128, 1, 1, C.byref(a)) == 2
     finally:
         ops.conv_impl()
     assert torch.equal(ref[0], got[0]) and torch.equal(ref[2], got[2])
@@ -767,7 +776,7 @@ def test_weight_stationary_conv_kernel_64ch(mode, Ln):
     the weight-stationary kernel: two column blocks x two row halves of a 128-row tile per workgroup,
     the statistics of the two halves added after the tile barrier; output bits == the one-tile kernel"""
     from speech_anonymization_amd import _lib as L, ops
-    d, B = dev(), 4
+    d, B = dev(), 6
     g = torch.Generator().manual_seed(17)
     x = torch.randn(B, Ln, 64, generator=g).to(d)
     w = (torch.randn(64, 64, 5, generator=g) * 0.07).to(d)
@@ -807,8 +816,8 @@ def test_weight_stationary_conv_kernel_64ch(mode, Ln):
 
 def test_weight_stationary_conv_routing():
     """what goes to the weight-stationary kernel: bf16x3 128->128 stride-1 5-tap launches with at
-    least 512 tiles and no pro_stats / second affine / fused backward epilogue / normalisation-
-    backward prologue; everything else to the one-tile kernel"""
+    least 1536 tiles (six per CU) and no fused backward epilogue / normalisation-backward prologue;
+    everything else to the one-tile kernel"""
     import ctypes as C
     from speech_anonymization_amd import _lib as L, ops
     lib = L.load()
@@ -819,8 +828,8 @@ def test_weight_stationary_conv_routing():
     route = lambda code=L.BF16X3, cin=128, cout=128: lib.sa_conv_gemm_route(code, cin, cout, 1, 1, C.byref(a))
     assert route() == 2
     assert route(L.F32) == 0 and route(L.BF16X3, 64, 128) == 0
-    a.B = 1
-    assert route() == 0                                              # 315 tiles: too few to fill the chip twice
+    a.B = 4
+    assert route() == 0                                              # 1260 tiles: under six per CU
     a.B = 32
     a.ep_mode = 1
     assert route() == 0

@@ -7,8 +7,8 @@ sys.path.insert(0, R)
 import torch
 from speech_anonymization_amd import _lib as L, ops
 dev = torch.device("cuda:0")
-B = int(sys.argv[1]) if len(sys.argv) > 1 else 3
-Ln = int(sys.argv[2]) if len(sys.argv) > 2 else 1000
+B = int(sys.argv[1]) if len(sys.argv) > 1 else 6          # >= 1536 tiles, or both arms run the one-tile kernel
+Ln = int(sys.argv[2]) if len(sys.argv) > 2 else 20160
 g = torch.Generator().manual_seed(3)
 x = torch.randn(B, Ln, 128, generator=g).to(dev)
 y2 = torch.randn(B, Ln, 128, generator=g).to(dev)
