@@ -596,8 +596,8 @@ int sa_pp_share(int cout);
 // same slab geometry as this file's 64-row tiles, so nothing else changes for the caller.
 // sa_conv_gemm_set_impl(0): this file's kernel only; (1): the ping-pong kernel for f32 / bf16x3.
 bool sa_conv_ws_covers(int dtype, int cin, int cout, int sa, int u, const SaConvArgs* a);
-int sa_conv_ws_dispatch(int cin, const SaConvArgs* a, hipStream_t st);
-int sa_conv_ws_tile_rows(int cin);
+int sa_conv_ws_dispatch(int cin, int cout, const SaConvArgs* a, hipStream_t st);
+int sa_conv_ws_tile_rows(int cout);
 static int g_use_pp = 0, g_use_ws = 1;
 extern "C" int sa_conv_gemm_set_impl(int impl) {
   if (impl < 0 || impl > 2) return -22;
@@ -669,8 +669,8 @@ extern "C" int sa_abi_sizeof(int which) {
 static int conv_route(int dtype, int cin, int cout, int sa, int u, const SaConvArgs* a) {
   if (uses_pp(dtype)) return 1;
   if (g_use_ws && sa_conv_ws_covers(dtype, cin, cout, sa, u, a) &&
-      tile_rows(cin, cout, u) == sa_conv_ws_tile_rows(cin) &&
-      (long)a->B * sa_div_up(a->Lout, sa_conv_ws_tile_rows(cin)) >= 1536)
+      tile_rows(cin, cout, u) == sa_conv_ws_tile_rows(cout) &&
+      (long)a->B * sa_div_up(a->Lout, sa_conv_ws_tile_rows(cout)) >= 1536)
     return 2;
   return 0;
 }
@@ -687,7 +687,7 @@ extern "C" int sa_conv_gemm(int dtype, int cin, int cout, int sa, int u, const S
   if (a->ep_mode < 0 || a->ep_mode > 2 || (a->ep_mode && !a->ep_x)) return -22;
   const int route = conv_route(dtype, cin, cout, sa, u, a);
   if (route == 1) return sa_conv_pp_dispatch(dtype, cin, cout, sa, u, a, st);
-  if (route == 2) return sa_conv_ws_dispatch(cin, a, st);
+  if (route == 2) return sa_conv_ws_dispatch(cin, cout, a, st);
   SA_CONV_CASE(32, 64, 2, 1)
   SA_CONV_CASE(64, 64, 1, 1)
   SA_CONV_CASE(64, 128, 2, 1)

@@ -814,6 +814,51 @@ def test_weight_stationary_conv_kernel_64ch(mode, Ln):
     assert rel_mse(got[0], yref) < 2e-9
 
 
+@pytest.mark.parametrize("Ln", [40320, 40003], ids=["train", "ragged"])
+@pytest.mark.parametrize("mode", ["plain", "swish_stats_cache"])
+def test_weight_stationary_conv_kernel_stride2(mode, Ln):
+    """encoder.8 (64 -> 128, stride 2: models/ConvAutoEncoder.py:149) on the weight-stationary kernel:
+    two staged input rows per output row (strided A-fragment rows), input side on 64 channels, output
+    side on 128; output bits == the one-tile kernel"""
+    from speech_anonymization_amd import _lib as L, ops
+    d, B = dev(), 6
+    g = torch.Generator().manual_seed(19)
+    x = torch.randn(B, Ln, 64, generator=g).to(d)
+    w = (torch.randn(128, 64, 5, generator=g) * 0.07).to(d)
+    bias = torch.randn(128, generator=g).to(d)
+    s1 = (torch.rand(B, 64, generator=g) + 0.5).to(d)
+    t1 = (torch.randn(B, 64, generator=g) * 0.1).to(d)
+    wp = ops.pack_weights(w, "conv_fwd", torch.float32, L.BF16X3)
+    Lout = (Ln + 4 - 5) // 2 + 1
+    kw = dict(code=L.BF16X3)
+    if mode != "plain":
+        kw.update(s1=s1, t1=t1, swish=True, want_stats=True)
+
+    def run(ws):
+        ops.conv_impl(ws=ws)
+        a_out = torch.full((B, Ln, 64), float("nan"), dtype=torch.bfloat16, device=d) if mode != "plain" else None
+        r = ops.conv_gemm(x, wp, bias, 64, 128, 2, 1, ops.taps_conv(5, 1, 2), Lout, a_out=a_out, **kw)
+        torch.cuda.synchronize()
+        return (r if isinstance(r, tuple) else (r,)) + ((a_out,) if a_out is not None else ())
+
+    try:
+        ref, got = run(False), run(True)
+        import ctypes as C
+        a = L.SaConvArgs()
+        a.B, a.Lin, a.Lout = B, Ln, Lout
+        a.taps = L.make_taps(ops.taps_conv(5, 1, 2))
+        assert L.load().sa_conv_gemm_route(L.BF16X3, 64, 128, 2, 1, C.byref(a)) == 2
+    finally:
+        ops.conv_impl()
+    assert torch.equal(ref[0], got[0])
+    if mode != "plain":
+        assert torch.allclose(ref[1], got[1], rtol=2e-6, atol=1e-3)
+        assert not torch.isnan(got[2].float()).any() and torch.equal(ref[2], got[2])
+    xin = torch.nn.functional.silu(x * s1[:, None, :] + t1[:, None, :]) if mode != "plain" else x
+    yref = F.conv1d(xin.permute(0, 2, 1), w, bias, stride=2, padding=2).permute(0, 2, 1)
+    assert rel_mse(got[0], yref) < 2e-9
+
+
 def test_weight_stationary_conv_routing():
     """what goes to the weight-stationary kernel: bf16x3 128->128 stride-1 5-tap launches with at
     least 1536 tiles (six per CU) and no fused backward epilogue / normalisation-backward prologue;
@@ -827,7 +872,7 @@ def test_weight_stationary_conv_routing():
     a.taps = L.make_taps(ops.taps_conv(5, 1, 2))
     route = lambda code=L.BF16X3, cin=128, cout=128: lib.sa_conv_gemm_route(code, cin, cout, 1, 1, C.byref(a))
     assert route() == 2
-    assert route(L.F32) == 0 and route(L.BF16X3, 64, 128) == 0
+    assert route(L.F32) == 0 and route(L.BF16X3, 64, 128) == 0 and route(L.BF16X3, 32, 64) == 0   # (64 -> 128 is a stride-2 layer)
     a.B = 4
     assert route() == 0                                              # 1260 tiles: under six per CU
     a.B = 32
