@@ -2,7 +2,8 @@
 // the stride-1 FORWARD launches with equal channel counts in the bf16x3 policy (fp32 storage, split-
 // bf16 operands): 128 -> 128, models/ConvAutoEncoder.py:150-158 (encoder.11), :161-166 (decoder.0) and
 // :33-43 (the three TDNN layers of the sex classifier: 5 taps, 3 taps dilation 2, 3 taps dilation 3);
-// 64 -> 64, :146-148 (encoder.5) and :167-169 (decoder.4); and the stride-2 layer 64 -> 128, :149 (encoder.8).
+// 64 -> 64, :146-148 (encoder.5) and :167-169 (decoder.4); the stride-2 layer 64 -> 128, :149 (encoder.8);
+// the transposed layer 128 -> 64, :161-163 (decoder.1), as two output phases.
 //
 // Same operation, arguments, statistics-slab geometry and output BITS as the 64-row one-tile kernel
 // (sa_conv_gemm.hip); different execution structure, chosen from the measurements in
@@ -69,16 +70,21 @@ namespace {
 // blocks of a 64-row tile, with 64 channels two column blocks x two row halves of a 128-row tile.
 // CO_ / SA_: output channels and input stride of the stride-2 encoder layer (64 -> 128: two input rows
 // per output row; everything on the input side -- staging, transform, operand planes -- keeps C_).
-template <int C_, int NT, int HALO_, int CO_ = C_, int SA_ = 1>
+// U_ = 2: a transposed layer (128 -> 64, stride 2) as two output phases of the same 64 base rows: the
+// two waves that share a column block are the two PHASES (output rows 2m and 2m+1, each with its own
+// taps; NT is the larger tap count, the other phase runs zero fragments for the missing tap).
+template <int C_, int NT, int HALO_, int CO_ = C_, int SA_ = 1, int U_ = 1>
 struct WsGeo {
-  static constexpr int C = C_, CO = CO_, SA = SA_, NTAPS = NT, HALO = HALO_;
-  static constexpr int NWN = CO_ / 32, NWM = 4 / NWN;      // waves along the columns / the rows
-  static constexpr int TM = 64 * NWM;                      // output rows per tile
+  static constexpr int C = C_, CO = CO_, SA = SA_, U = U_, NTAPS = NT, HALO = HALO_;
+  static constexpr int NWN = CO_ / 32, NWM = 4 / NWN;      // waves along the columns / the rows (or phases)
+  static_assert(U_ == 1 || NWM == 2, "two phases = the two waves of a column block");
+  static constexpr int BM = U_ == 2 ? 64 : 64 * NWM;       // base (input-grid) rows per tile
+  static constexpr int TM = BM * U_;                       // output rows per tile
   static constexpr int KSTEPS = C_ / 16;
   static constexpr int PITCH = C_ + 8;                     // bf16 elements per LDS operand row (conflict-free ds_read_b128)
   static constexpr int RPP = 256 / C_;                     // rows per 1-KiB DMA piece (2 or 4)
   static constexpr int LPR = 64 / RPP;                     // lanes per row of a piece (4 channels each)
-  static constexpr int ROWS = ((TM - 1) * SA_ + 1 + HALO_ + RPP - 1) / RPP * RPP;   // staged input rows per tile, whole DMA pieces
+  static constexpr int ROWS = ((BM - 1) * SA_ + 1 + HALO_ + RPP - 1) / RPP * RPP;   // staged input rows per tile, whole DMA pieces
   static constexpr int PLANE = ROWS * PITCH;               // bf16 elements per plane
   static constexpr int NDMA = ROWS / RPP;                  // 1-KiB DMA pieces per tile and tensor
   static constexpr int DPW = (NDMA + 3) / 4;               // pieces per wave (the last waves have one less)
@@ -161,11 +167,12 @@ __device__ __forceinline__ void ws_static_for(F&& f) {
 // 3: mode 1 + pro_stats (per-tile sum / sum of squares of the transformed rows the tile owns),
 // 4: mode 1 + a second, per-channel affine (the classifier's input BatchNorm behind the activation)
 // 5: one per-channel affine only (the dilated TDNN layers: BatchNorm of the layer below in front)
-template <int MODE, int NT, int HALO, int CC = 128, int CO = CC, int SA = 1>
+template <int MODE, int NT, int HALO, int CC = 128, int CO = CC, int SA = 1, int UU = 1>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1)))
 void sa_conv_ws_kernel(SaConvArgs a, int tiles_per_wg, int total_tiles) {
-  typedef WsGeo<CC, NT, HALO, CO, SA> G;
-  constexpr int WS_CO = G::CO, WS_SA = G::SA;
+  typedef WsGeo<CC, NT, HALO, CO, SA, UU> G;
+  constexpr int WS_CO = G::CO, WS_SA = G::SA, WS_BM = G::BM;
+  static_assert(UU == 1 || MODE == 0, "transposed layers: plain rows");
   constexpr int WS_C = G::C, WS_TM = G::TM, WS_KSTEPS = G::KSTEPS, WS_PITCH = G::PITCH, RPP = G::RPP, LPR = G::LPR,
                 NWN = G::NWN, NWM = G::NWM;
   static_assert(CC == 128 || MODE == 0 || MODE == 1, "64 channels: plain and affine + x*sigmoid(x) prologues");
@@ -185,7 +192,9 @@ void sa_conv_ws_kernel(SaConvArgs a, int tiles_per_wg, int total_tiles) {
   const unsigned raw_lds = (unsigned)(uintptr_t)(lds_byte*)raw;
   const int tid = threadIdx.x, lane_ = tid & 63;
   const int wave_ = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wn_ = wave_ % NWN, wm_ = wave_ / NWN;           // this wave's column block / row half of the tile
+  const int wn_ = wave_ % NWN, wm_ = wave_ / NWN;           // this wave's column block / row half (or phase) of the tile
+  const int ph_ = UU == 2 ? wm_ : 0, rh_ = UU == 2 ? 0 : wm_;   // output phase, row half
+  const int ntap_ = a.taps.ntaps[ph_];                      // (transposed layers: 3 and 2)
   const int first = blockIdx.x * tiles_per_wg;
   int last = first + tiles_per_wg;
   if (last > total_tiles) last = total_tiles;
@@ -197,11 +206,16 @@ void sa_conv_ws_kernel(SaConvArgs a, int tiles_per_wg, int total_tiles) {
     const bf16x8* wp = reinterpret_cast<const bf16x8*>(a.wp);
 #pragma unroll
     for (int t = 0; t < WS_NTAPS; ++t) {
-      const bf16x8* wt = wp + ((size_t)a.taps.widx[0][t] * WS_KSTEPS * NWN + wn_) * 64 + lane_;
+      const bool has_t = UU == 1 || t < ntap_;
+      const bf16x8* wt = wp + ((size_t)a.taps.widx[ph_][has_t ? t : 0] * WS_KSTEPS * NWN + wn_) * 64 + lane_;
 #pragma unroll
       for (int k = 0; k < WS_KSTEPS; ++k) {
         Bh[t][k] = wt[(size_t)k * NWN * 64];
         Bl[t][k] = wt[(size_t)a.wlo_off + (size_t)k * NWN * 64];
+        if (UU == 2 && !has_t) {                           // the phase with fewer taps: zero fragments
+          Bh[t][k] = bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
+          Bl[t][k] = bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
+        }
       }
       // one tap at a time, moved to its AGPR home before the next tap is fetched (all 80 loads at
       // once would need 320 VGPRs).  The empty asm also makes hipcc wait for the loads HERE: a value
@@ -229,7 +243,8 @@ void sa_conv_ws_kernel(SaConvArgs a, int tiles_per_wg, int total_tiles) {
   unsigned raw_off = wave_ * 1024 + lane_ * 16;            // byte offset in the raw tile: + j*4096
   unsigned pl_off = (row0 * WS_PITCH + cq_ * 4) * 2;       // byte offset in an operand plane: + j*4*RPP*PITCH*2
   unsigned ao_off = (row0 * WS_C + cq_ * 4) * 2;           // byte offset in the a_out row block: + j*4*RPP*C*2
-  unsigned y_off = ((4 * half_ + 64 * wm_) * WS_CO + wn_ * 32 + l31_) * 4;  // byte offset in the y row block: + ro*CO*4
+  unsigned y_off = (UU == 2 ? (8 * half_ + ph_) * WS_CO + wn_ * 32 + l31_          // phase rows 2(ro + 4 half) + ph: + 2*ro*CO*4
+                            : (4 * half_ + 64 * rh_) * WS_CO + wn_ * 32 + l31_) * 4;  // byte offset in the y row block: + ro*CO*4
   unsigned st_off = (wn_ * 32 + l31_) * 8;                 // byte offset of this lane's column in a statistics slab
   unsigned swap_off = (lane_ ^ 32) * 4;                    // ds_bpermute address of the lane in the other half
   asm volatile("" : "+v"(bv), "+v"(relu_floor), "+v"(row0), "+v"(dma_off), "+v"(raw_off), "+v"(pl_off), "+v"(ao_off), "+v"(y_off),
@@ -243,7 +258,7 @@ void sa_conv_ws_kernel(SaConvArgs a, int tiles_per_wg, int total_tiles) {
   auto next_tile = [&](Tile T) { Tile r; const bool wrap = T.tile + 1 == a.ntiles; r.b = wrap ? T.b + 1 : T.b; r.tile = wrap ? 0 : T.tile + 1; return r; };
   // rows outside the utterance among the 68 staged ones, or the trailing rows it owns beyond its 64
   auto is_edge = [&](Tile T) {
-    const int g0 = T.tile * (WS_TM * WS_SA) + a.rowmin;
+    const int g0 = T.tile * (WS_BM * WS_SA) + a.rowmin;
     return g0 < 0 || g0 + WS_ROWS > a.Lin || T.tile == a.ntiles - 1;
   };
 
@@ -294,7 +309,7 @@ void sa_conv_ws_kernel(SaConvArgs a, int tiles_per_wg, int total_tiles) {
   auto dma_piece = [&](Tile T, bool edge, int j, int part = 2) {
     const int i = wave_ + 4 * j;
     if (j == WS_DPW - 1 && i >= WS_NDMA) return;
-    const int g0 = T.tile * (WS_TM * WS_SA) + a.rowmin;
+    const int g0 = T.tile * (WS_BM * WS_SA) + a.rowmin;
     if (!edge) {
       if (part != 1) ws_dma16s(xbase_d + j * 4096, dma_off, raw_lds + i * 1024);
       if constexpr (PRO2) {
@@ -323,8 +338,8 @@ void sa_conv_ws_kernel(SaConvArgs a, int tiles_per_wg, int total_tiles) {
     }
   };
   auto own_range = [&](Tile T, int& lo, int& hi) {
-    lo = T.tile * (WS_TM * WS_SA);
-    hi = T.tile == a.ntiles - 1 ? a.Lin : lo + WS_TM * WS_SA;
+    lo = T.tile * (WS_BM * WS_SA);
+    hi = T.tile == a.ntiles - 1 ? a.Lin : lo + WS_BM * WS_SA;
     if (hi > a.Lin) hi = a.Lin;
   };
   // is this lane's row of piece j one the tile owns (operand cache, column sums)?  interior tiles:
@@ -333,11 +348,11 @@ void sa_conv_ws_kernel(SaConvArgs a, int tiles_per_wg, int total_tiles) {
     if (!edge) {                                           // own rows = staged rows [-rowmin, -rowmin + TM)
       if (j > 0 && j < WS_DPW - 2) return true;            // the middle pieces are owned in every geometry
       const int r = (int)row0 + 4 * RPP * j;               // (per lane where a piece straddles the boundary)
-      return r >= -a.rowmin && r < -a.rowmin + WS_TM * WS_SA;
+      return r >= -a.rowmin && r < -a.rowmin + WS_BM * WS_SA;
     }
     int lo, hi;
     own_range(T, lo, hi);
-    const int g = T.tile * (WS_TM * WS_SA) + a.rowmin + (int)row0 + 4 * RPP * j;
+    const int g = T.tile * (WS_BM * WS_SA) + a.rowmin + (int)row0 + 4 * RPP * j;
     return g >= lo && g < hi;
   };
   // hi = bf16(v), lo = bf16(v - hi) of a channel pair (same roundings as sa_split4)
@@ -368,7 +383,7 @@ void sa_conv_ws_kernel(SaConvArgs a, int tiles_per_wg, int total_tiles) {
       if (a.nb_colsum && owns(T, edge, j)) csum[q] += v;
     }
     if (edge) {                                            // rows outside the utterance are zero operands
-      const int g = T.tile * (WS_TM * WS_SA) + a.rowmin + (int)row0 + 4 * RPP * j;
+      const int g = T.tile * (WS_BM * WS_SA) + a.rowmin + (int)row0 + 4 * RPP * j;
       if (!(g >= 0 && g < a.Lin)) v = 0.0f;
     }
     f[q] = v;
@@ -492,7 +507,7 @@ void sa_conv_ws_kernel(SaConvArgs a, int tiles_per_wg, int total_tiles) {
   auto epi_store = [&](int n) {                             // slot form, full tiles: the store of value n
     const int m = n >> 4, i = n & 15;
     const int ro = m * 32 + (i & 3) + 8 * (i >> 2);         // row in the tile, before the lane half's +4
-    if constexpr ((SA_ABL & 64) == 0) ws_store_b32(ybase_e + ro * (WS_CO * 4), y_off, eval);   // (64: timing-only build without the stores)
+    if constexpr ((SA_ABL & 64) == 0) ws_store_b32(ybase_e + ro * (UU * WS_CO * 4), y_off, eval);   // (64: timing-only build without the stores)
   };
   auto epi_accum = [&](int n) {                             // ... its statistics, and value n+1 formed
     // (asm: hipcc otherwise sinks all 32 accumulations into the statistics slot, behind its branch)
@@ -508,8 +523,9 @@ void sa_conv_ws_kernel(SaConvArgs a, int tiles_per_wg, int total_tiles) {
       const int m = n >> 4, i = n & 15;
       const int ro = m * 32 + (i & 3) + 8 * (i >> 2);
       const float val = epi_form(n);
-      if (T.tile * WS_TM + 64 * wm_ + ro + 4 * (lane >> 5) < a.Lout) {
-        *reinterpret_cast<float*>(ybase_e + ro * (WS_CO * 4) + y_off) = val;
+      const int orow = UU == 2 ? 2 * (ro + 4 * (lane >> 5)) + ph_ : 64 * rh_ + ro + 4 * (lane >> 5);
+      if (T.tile * WS_TM + orow < a.Lout) {
+        *reinterpret_cast<float*>(ybase_e + ro * (UU * WS_CO * 4) + y_off) = val;
         ssum += val; ssq = fmaf(val, val, ssq);
       }
     }
@@ -553,7 +569,7 @@ void sa_conv_ws_kernel(SaConvArgs a, int tiles_per_wg, int total_tiles) {
 
   int toff[WS_NTAPS];
 #pragma unroll
-  for (int t = 0; t < WS_NTAPS; ++t) toff[t] = (a.taps.off[0][t] - a.rowmin) * WS_PITCH;
+  for (int t = 0; t < WS_NTAPS; ++t) toff[t] = (a.taps.off[ph_][UU == 1 || t < ntap_ ? t : 0] - a.rowmin) * WS_PITCH;
 
   // ================= prologue: first tile staged without overlap =================
   // Past the end of the range the "next" tiles are clamped to its last one: the transform / DMA
@@ -563,14 +579,14 @@ void sa_conv_ws_kernel(SaConvArgs a, int tiles_per_wg, int total_tiles) {
   for (int q = 0; q < 4; ++q) { csum[q] = 0.0f; csq[q] = 0.0f; }
   {
     const bool ec = is_edge(Tc), en = is_edge(Tn);
-    xbase_d = row_block(a.x, Tc.b, a.Lin, Tc.tile * (WS_TM * WS_SA) + a.rowmin, WS_C * 4);
-    if constexpr (PRO2) x2base_d = row_block(a.nb_x, Tc.b, a.Lin, Tc.tile * (WS_TM * WS_SA) + a.rowmin, WS_C * 4);
-    aobase_t = const_cast<char*>(row_block(a.a_out, Tc.b, a.Lin, Tc.tile * (WS_TM * WS_SA) + a.rowmin, WS_C * 2));
+    xbase_d = row_block(a.x, Tc.b, a.Lin, Tc.tile * (WS_BM * WS_SA) + a.rowmin, WS_C * 4);
+    if constexpr (PRO2) x2base_d = row_block(a.nb_x, Tc.b, a.Lin, Tc.tile * (WS_BM * WS_SA) + a.rowmin, WS_C * 4);
+    aobase_t = const_cast<char*>(row_block(a.a_out, Tc.b, a.Lin, Tc.tile * (WS_BM * WS_SA) + a.rowmin, WS_C * 2));
     pl_cur = pl_off;
 #pragma unroll
     for (int j = 0; j < WS_DPW; ++j) dma_piece(Tc, ec, j);
-    xbase_d = row_block(a.x, Tn.b, a.Lin, Tn.tile * (WS_TM * WS_SA) + a.rowmin, WS_C * 4);
-    if constexpr (PRO2) x2base_d = row_block(a.nb_x, Tn.b, a.Lin, Tn.tile * (WS_TM * WS_SA) + a.rowmin, WS_C * 4);
+    xbase_d = row_block(a.x, Tn.b, a.Lin, Tn.tile * (WS_BM * WS_SA) + a.rowmin, WS_C * 4);
+    if constexpr (PRO2) x2base_d = row_block(a.nb_x, Tn.b, a.Lin, Tn.tile * (WS_BM * WS_SA) + a.rowmin, WS_C * 4);
     if (SWISH || PRO2) load_consts(Tc.b);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #pragma unroll
@@ -596,7 +612,7 @@ void sa_conv_ws_kernel(SaConvArgs a, int tiles_per_wg, int total_tiles) {
   for (int t = first, it = 0; t < last; ++t, ++it) {
     int lanem = lane_;
     asm volatile("" : "+v"(lanem));
-    const bf16_t* ab = planes + (size_t)(it & 1) * 2 * WS_PLANE + ((lanem & 31) + 64 * wm_) * (WS_SA * WS_PITCH) + (lanem >> 5) * 8;
+    const bf16_t* ab = planes + (size_t)(it & 1) * 2 * WS_PLANE + ((lanem & 31) + 64 * rh_) * (WS_SA * WS_PITCH) + (lanem >> 5) * 8;
     // A fragments of the next step, read behind MFMAs 0 and 1 of this one, i.e. four MFMAs or more
     // ahead of their use (hipcc waits for all of them once, in front of the next step's MFMA 0): the
     // lo halves (MFMAs 0, 1) have one slot, refilled behind their last use, the hi halves (2..5) two
@@ -620,9 +636,9 @@ void sa_conv_ws_kernel(SaConvArgs a, int tiles_per_wg, int total_tiles) {
     // its bounds-checked epilogue in front of it, not overlapped
     const bool slotE = doE && !partialE, slotT = !edgeT, slotD = !edgeT && !edgeD;
     if ((SWISH || PRO2) && Tn.b != cur_b) load_consts(Tn.b);
-    xbase_d = row_block(a.x, Tnn.b, a.Lin, Tnn.tile * (WS_TM * WS_SA) + a.rowmin, WS_C * 4);
-    if constexpr (PRO2) x2base_d = row_block(a.nb_x, Tnn.b, a.Lin, Tnn.tile * (WS_TM * WS_SA) + a.rowmin, WS_C * 4);
-    aobase_t = const_cast<char*>(row_block(a.a_out, Tn.b, a.Lin, Tn.tile * (WS_TM * WS_SA) + a.rowmin, WS_C * 2));
+    xbase_d = row_block(a.x, Tnn.b, a.Lin, Tnn.tile * (WS_BM * WS_SA) + a.rowmin, WS_C * 4);
+    if constexpr (PRO2) x2base_d = row_block(a.nb_x, Tnn.b, a.Lin, Tnn.tile * (WS_BM * WS_SA) + a.rowmin, WS_C * 4);
+    aobase_t = const_cast<char*>(row_block(a.a_out, Tn.b, a.Lin, Tn.tile * (WS_BM * WS_SA) + a.rowmin, WS_C * 2));
     ybase_e = const_cast<char*>(row_block(a.y, Tp.b, a.Lout, Tp.tile * WS_TM, WS_CO * 4));
     stbase_e = const_cast<char*>(row_block(a.stats, Tp.b, a.ntiles, Tp.tile, WS_CO * 8));
     pl_cur = (it + 1) & 1 ? pl_off + WS_BUF_BYTES : pl_off;
@@ -814,30 +830,31 @@ void sa_conv_ws_kernel(SaConvArgs a, int tiles_per_wg, int total_tiles) {
 #undef WS_IDS
 }
 
-template <int MODE, int NT = 5, int HALO = 4, int CC = 128, int CO = CC, int SA = 1>
+template <int MODE, int NT = 5, int HALO = 4, int CC = 128, int CO = CC, int SA = 1, int UU = 1>
 int launch_ws(const SaConvArgs& a, hipStream_t st) {
-  typedef WsGeo<CC, NT, HALO, CO, SA> G;
+  typedef WsGeo<CC, NT, HALO, CO, SA, UU> G;
   constexpr int WS_NTAPS = G::NTAPS, WS_HALO = G::HALO, WS_ROWS = G::ROWS, WS_RAW_BYTES = G::RAW_BYTES, WS_BUF_BYTES = G::BUF_BYTES,
-                WS_C = G::C, WS_TM = G::TM, WS_KSTEPS = G::KSTEPS;
+                WS_C = G::C, WS_KSTEPS = G::KSTEPS;
   SaConvArgs args = a;
-  args.ntiles = sa_div_up(a.Lout, WS_TM);
+  args.ntiles = sa_div_up(sa_div_up(a.Lout, UU), G::BM);
   int omin = 1 << 30, omax = -(1 << 30), wmax = 0;
-  for (int t = 0; t < WS_NTAPS; ++t) {
-    omin = a.taps.off[0][t] < omin ? a.taps.off[0][t] : omin;
-    omax = a.taps.off[0][t] > omax ? a.taps.off[0][t] : omax;
-    wmax = a.taps.widx[0][t] > wmax ? a.taps.widx[0][t] : wmax;
-  }
+  for (int ph = 0; ph < UU; ++ph)
+    for (int t = 0; t < (UU == 1 ? WS_NTAPS : a.taps.ntaps[ph]); ++t) {
+      omin = a.taps.off[ph][t] < omin ? a.taps.off[ph][t] : omin;
+      omax = a.taps.off[ph][t] > omax ? a.taps.off[ph][t] : omax;
+      wmax = a.taps.widx[ph][t] > wmax ? a.taps.widx[ph][t] : wmax;
+    }
   if (omax - omin != WS_HALO) return -22;
   args.rowmin = omin;
   args.nrows = WS_ROWS;
   args.wlo_off = (wmax + 1) * WS_KSTEPS * G::NWN * 64;   // fragment units: size of the hi image
   if ((a.a_out || a.nb_colsum || a.pro_stats) &&
-      (omin > 0 || omax < 0 || (args.ntiles - 1) * WS_TM * SA + omin + WS_ROWS < a.Lin))
+      (omin > 0 || omax < 0 || (args.ntiles - 1) * G::BM * SA + omin + WS_ROWS < a.Lin))
     return -22;                                           // every input row must be staged by the tile that owns it
   if ((long)a.B * a.Lin >= (1L << 31) - 64 || (long)a.B * a.Lout >= (1L << 31) - 64) return -22;   // 32-bit row indices in the kernel
   const size_t lds = 2 * WS_BUF_BYTES + (MODE == 2 ? 2 : 1) * WS_RAW_BYTES +
                      (MODE == 2 ? 2 * 4 * WS_C * 4 : MODE == 3 ? 2 * 4 * WS_C * 8 : G::NWM == 2 ? 2 * 4 * 32 * 8 : 0);
-  auto kern = sa_conv_ws_kernel<MODE, NT, HALO, CC, CO, SA>;
+  auto kern = sa_conv_ws_kernel<MODE, NT, HALO, CC, CO, SA, UU>;
   static bool attr_set = false;
   static int n_cu = 0;
   if (!attr_set) {
@@ -862,6 +879,18 @@ int launch_ws(const SaConvArgs& a, hipStream_t st) {
 
 // Does the weight-stationary kernel serve this launch?  (sa_conv_gemm.hip asks before routing.)
 bool sa_conv_ws_covers(int dtype, int cin, int cout, int sa, int u, const SaConvArgs* a) {
+  if (dtype == SA_BF16X3 && cin == 128 && cout == 64 && sa == 1 && u == 2) {    // decoder.1: transposed, 128 -> 64
+    if (a->taps.ntaps[0] > 3 || a->taps.ntaps[1] > 3 || a->taps.ntaps[0] < 1 || a->taps.ntaps[1] < 1) return false;
+    int lo = 1 << 30, hi = -(1 << 30);
+    for (int ph = 0; ph < 2; ++ph)
+      for (int t = 0; t < a->taps.ntaps[ph]; ++t) {
+        lo = a->taps.off[ph][t] < lo ? a->taps.off[ph][t] : lo;
+        hi = a->taps.off[ph][t] > hi ? a->taps.off[ph][t] : hi;
+      }
+    if (hi - lo != 2 || lo > 0 || hi < 0) return false;
+    if (a->tile_rows && a->tile_rows != 128) return false;
+    return !a->s1 && !a->swish && !a->s2 && !a->t2 && !a->pro_stats && !a->nb_x && !a->ep_mode && !a->wscale && !a->relu;
+  }
   const bool s2layer = cin == 64 && cout == 128 && sa == 2;                // encoder.8: 64 -> 128, stride 2
   if (dtype != SA_BF16X3 || u != 1 || !(s2layer || (cin == cout && sa == 1 && (cin == 128 || cin == 64)))) return false;
   const int nt = a->taps.ntaps[0];
@@ -896,6 +925,7 @@ bool sa_conv_ws_covers(int dtype, int cin, int cout, int sa, int u, const SaConv
 int sa_conv_ws_tile_rows(int cout) { return cout == 64 ? 128 : 64; }
 
 int sa_conv_ws_dispatch(int cin, int cout, const SaConvArgs* a, hipStream_t st) {
+  if (cin == 128 && cout == 64) return launch_ws<0, 3, 2, 128, 64, 1, 2>(*a, st);
   if (cin == 64 && cout == 128) return a->s1 ? launch_ws<1, 5, 4, 64, 128, 2>(*a, st) : launch_ws<0, 5, 4, 64, 128, 2>(*a, st);
   if (cin == 64) return a->s1 ? launch_ws<1, 5, 4, 64>(*a, st) : launch_ws<0, 5, 4, 64>(*a, st);
   if (a->taps.ntaps[0] == 3) {
