@@ -902,6 +902,60 @@ def test_weight_stationary_conv_kernel_transposed(mode, Lin):
     assert rel_mse(got[0], yref) < 2e-9
 
 
+def test_weight_stationary_conv_kernel_random_lengths():
+    """seeded sweep over utterance counts and lengths (tile ranges that start / end anywhere inside an
+    utterance, partial last tiles, single-tile tails) for every layer form the weight-stationary kernel
+    serves: output, statistics slabs and operand cache against the one-tile kernel"""
+    import ctypes as C
+    import random
+    from speech_anonymization_amd import _lib as L, ops
+    d = dev()
+    rng = random.Random(20260401)
+    # (cin, cout, sa, u, taps-or-phases, weight kind, weight shape, base length range)
+    forms = [
+        (128, 128, 1, 1, lambda: ops.taps_conv(5, 1, 2), "conv_fwd", (128, 128, 5), (17000, 21000), True),
+        (128, 128, 1, 1, lambda: ops.taps_conv(3, 3, 0), "conv_fwd", (128, 128, 3), (17000, 21000), False),
+        (64, 64, 1, 1, lambda: ops.taps_conv(5, 1, 2), "conv_fwd", (64, 64, 5), (34000, 41000), True),
+        (64, 128, 2, 1, lambda: ops.taps_conv(5, 1, 2), "conv_fwd", (128, 64, 5), (34000, 41000), True),
+        (128, 64, 1, 2, lambda: ops.UP2, "convT_fwd", (128, 64, 5), (17000, 21000), False),
+    ]
+    try:
+        for cin, cout, sa, u, mk, kind, wshape, (lo, hi), swish in forms:
+            for _ in range(2):
+                B, Lin = rng.randint(6, 9), rng.randint(lo, hi)
+                taps = mk()
+                offs = [o for ph in taps for (o, _) in ph]
+                Lout = 2 * Lin if u == 2 else (Lin + (-2 * min(offs) if min(offs) < 0 else 0) - (max(offs) - min(offs)) - 1) // sa + 1
+                if u == 1 and min(offs) == 0:
+                    Lout = (Lin - max(offs) - 1) // sa + 1
+                g = torch.Generator().manual_seed(rng.randint(0, 1 << 30))
+                x = torch.randn(B, Lin, cin, generator=g).to(d)
+                w = (torch.randn(*wshape, generator=g) * 0.06).to(d)
+                bias = torch.randn(cout, generator=g).to(d)
+                s1 = (torch.rand(B, cin, generator=g) + 0.5).to(d)
+                t1 = (torch.randn(B, cin, generator=g) * 0.1).to(d)
+                wp = ops.pack_weights(w, kind, torch.float32, L.BF16X3)
+                kw = dict(s1=s1, t1=t1, swish=True) if swish else {}
+                outs = []
+                for ws in (False, True):
+                    ops.conv_impl(ws=ws)
+                    a_out = torch.full((B, Lin, cin), float("nan"), dtype=torch.bfloat16, device=d)
+                    y, st = ops.conv_gemm(x, wp, bias, cin, cout, sa, u, taps, Lout, want_stats=True, code=L.BF16X3,
+                                          a_out=a_out, **kw)
+                    torch.cuda.synchronize()
+                    outs.append((y, st, a_out))
+                a = L.SaConvArgs()
+                a.B, a.Lin, a.Lout = B, Lin, Lout
+                a.taps = L.make_taps(taps)
+                case = (cin, cout, sa, u, B, Lin, Lout)
+                assert L.load().sa_conv_gemm_route(L.BF16X3, cin, cout, sa, u, C.byref(a)) == 2, case
+                assert torch.equal(outs[0][0], outs[1][0]), case
+                assert torch.equal(outs[0][2], outs[1][2]) and not torch.isnan(outs[1][2].float()).any(), case
+                assert torch.allclose(outs[0][1], outs[1][1], rtol=2e-6, atol=1e-3), case
+    finally:
+        ops.conv_impl()
+
+
 def test_weight_stationary_conv_routing():
     """what goes to the weight-stationary kernel: bf16x3 128->128 stride-1 5-tap launches with at
     least 1536 tiles (six per CU) and no fused backward epilogue / normalisation-backward prologue;
