@@ -1,5 +1,5 @@
 """Diagnostic build (-DSA_WS_STAMPS): where wave 0 of one workgroup of sa_conv_ws spends each tile
-(s_memtime; 100 MHz constant clock x ... see the printed calibration).  python tools/ws_stamps.py [plain|fwd|nb]"""
+(s_memtime ticks = shader cycles; the printed ns per tick is the clock the chip held under the kernel).  python tools/ws_stamps.py [plain|fwd|nb]"""
 import sys, os, ctypes as C, subprocess
 R = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, R)
@@ -63,7 +63,7 @@ n = int((a[:, 0] > 0).sum())
 span = a[n - 1, 0] - a[0, 0]
 print(f"ABL={abl} {which}: {us:.1f} us per launch; workgroup 7: {n - 1} tiles in {span:.0f} ticks "
       f"=> {span / (n - 1):.0f} ticks per tile, {us * 1e3 / span:.3f} ns per tick if the workgroup spans the launch")
-print("per tile (ticks): slots 0..32 (epilogue) | slots 33..55 (MFMA only) | vmcnt(0) wait | slots 56..119 (transform + DMA) | nops, copy, barrier | total")
+print("per tile (ticks): epilogue slots 0..33 | empty slots up to FT-1 | counted vmcnt wait | transform + DMA slots FT.. | wait states, accumulator copy, barrier, scalar set-up | total")
 for it in range(min(n - 1, int(os.environ.get("WS_ROWS", "12")))):
     r = a[it]
     nxt = a[it + 1, 0]
