@@ -107,7 +107,7 @@ int sa_conv_gemm_set_tile_rows(int rows);   /* tuning knob: 0 (default policy), 
  * kernel choice below (the ping-pong kernel writes one slab per wave that shares a column block). */
 int sa_conv_gemm_geometry(int dtype, int cin, int cout, int u, int Lout, int* ntiles, int* nslabs);
 /* Kernel choice of sa_conv_gemm, process-wide.  2 (default): the weight-stationary kernel
- * (sa_conv_ws.hip) serves the bf16x3 128->128, 64->64 stride-1, 64->128 stride-2 and 128->64 transposed launches with >= 1536 tiles that it
+ * (sa_conv_ws.hip) serves the bf16x3 128->128, 64->64 stride-1, 64->128 stride-2 and 128->64 / 64->32 transposed launches with >= 1536 tiles that it
  * covers (5 taps at unit spacing, 128 channels also 3 taps over 4 / 6 rows; no fused backward
  * epilogue, no normalisation-backward prologue), the one-tile-per-workgroup kernel everything else -- same geometry and, given the same
  * inputs, the same output bits.  0: one-tile kernel only.  1: the ping-pong kernel (sa_conv_pp.hip)

@@ -598,6 +598,7 @@ int sa_pp_share(int cout);
 bool sa_conv_ws_covers(int dtype, int cin, int cout, int sa, int u, const SaConvArgs* a);
 int sa_conv_ws_dispatch(int cin, int cout, const SaConvArgs* a, hipStream_t st);
 int sa_conv_ws_tile_rows(int cout);
+int sa_conv_ws_rows_per_tile(int cout);
 static int g_use_pp = 0, g_use_ws = 1;
 extern "C" int sa_conv_gemm_set_impl(int impl) {
   if (impl < 0 || impl > 2) return -22;
@@ -670,7 +671,7 @@ static int conv_route(int dtype, int cin, int cout, int sa, int u, const SaConvA
   if (uses_pp(dtype)) return 1;
   if (g_use_ws && sa_conv_ws_covers(dtype, cin, cout, sa, u, a) &&
       tile_rows(cin, cout, u) == sa_conv_ws_tile_rows(cout) &&
-      (long)a->B * sa_div_up(a->Lout, sa_conv_ws_tile_rows(cout)) >= 1536)
+      (long)a->B * sa_div_up(a->Lout, sa_conv_ws_rows_per_tile(cout)) >= 1536)
     return 2;
   return 0;
 }

@@ -3,7 +3,7 @@
 // bf16 operands): 128 -> 128, models/ConvAutoEncoder.py:150-158 (encoder.11), :161-166 (decoder.0) and
 // :33-43 (the three TDNN layers of the sex classifier: 5 taps, 3 taps dilation 2, 3 taps dilation 3);
 // 64 -> 64, :146-148 (encoder.5) and :167-169 (decoder.4); the stride-2 layer 64 -> 128, :149 (encoder.8);
-// the transposed layer 128 -> 64, :161-163 (decoder.1), as two output phases.
+// the transposed layers 128 -> 64, :161-163 (decoder.1), and 64 -> 32, :170-172 (decoder.5), as two output phases.
 //
 // Same operation, arguments, statistics-slab geometry and output BITS as the 64-row one-tile kernel
 // (sa_conv_gemm.hip); different execution structure, chosen from the measurements in
@@ -77,8 +77,12 @@ template <int C_, int NT, int HALO_, int CO_ = C_, int SA_ = 1, int U_ = 1>
 struct WsGeo {
   static constexpr int C = C_, CO = CO_, SA = SA_, U = U_, NTAPS = NT, HALO = HALO_;
   static constexpr int NWN = CO_ / 32, NWM = 4 / NWN;      // waves along the columns / the rows (or phases)
-  static_assert(U_ == 1 || NWM == 2, "two phases = the two waves of a column block");
-  static constexpr int BM = U_ == 2 ? 64 : 64 * NWM;       // base (input-grid) rows per tile
+  static_assert(U_ == 1 || NWM == 2 || NWM == 4, "two phases = wave pairs of a column block");
+  static constexpr int RHW = NWM / U_;                     // row halves (64 base rows each) of a tile
+  static constexpr int BM = 64 * RHW;                      // base (input-grid) rows per tile
+  // statistics slabs per tile (the one-tile kernel's tiles are 128 output rows for these shapes: a
+  // transposed tile with two row halves spans two of them) and waves whose sums share a slab entry
+  static constexpr int SLABS = U_ == 2 ? RHW : 1, COMBINE = NWM / SLABS;
   static constexpr int TM = BM * U_;                       // output rows per tile
   static constexpr int KSTEPS = C_ / 16;
   static constexpr int PITCH = C_ + 8;                     // bf16 elements per LDS operand row (conflict-free ds_read_b128)
@@ -98,7 +102,7 @@ struct WsGeo {
   // instructions of a piece (raw read, operand-plane writes) then always sit in slots 0 / 1 of a step,
   // four MFMAs ahead of the lgkmcnt(0) that hipcc puts in front of the next step's first MFMA.  The
   // epilogue takes slots 0..33 (one accumulator register per slot, then the statistics).
-  static constexpr int SUBS = NSLOT == 120 ? 6 : NT == 5 ? 18 : 12;   // (64 input channels: 120 slots per tile, levels in pairs)
+  static constexpr int SUBS = NSLOT == 72 ? 4 : NSLOT == 120 ? 6 : NT == 5 ? 18 : 12;   // (64 input channels: 120 / 72 slots per tile, levels packed)
   static constexpr int FT = NSLOT - SUBS * DPW;            // first transform slot
   static_assert(FT > 34 && FT % 6 == 0, "epilogue slots / step alignment");
 };
@@ -179,7 +183,7 @@ void sa_conv_ws_kernel(SaConvArgs a, int tiles_per_wg, int total_tiles) {
   constexpr int WS_NTAPS = G::NTAPS, WS_ROWS = G::ROWS, WS_PLANE = G::PLANE, WS_NDMA = G::NDMA, WS_DPW = G::DPW,
                 WS_RAW_BYTES = G::RAW_BYTES, WS_BUF_BYTES = G::BUF_BYTES, WS_NAGPR_FRAGS = G::NAGPR_FRAGS,
                 WS_FT = G::FT, WS_SUBS = G::SUBS;
-  (void)WS_ROWS;
+  (void)WS_ROWS; (void)NWM;
   static_assert(MODE == 0 || MODE == 5 || NT == 5, "the staged transforms need the 240-slot tile");
   constexpr bool PRO2 = MODE == 2;
   constexpr bool SWISH = MODE == 1 || MODE == 3 || MODE == 4;   // affine (per utterance, channel) + x*sigmoid(x)
@@ -193,7 +197,7 @@ void sa_conv_ws_kernel(SaConvArgs a, int tiles_per_wg, int total_tiles) {
   const int tid = threadIdx.x, lane_ = tid & 63;
   const int wave_ = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wn_ = wave_ % NWN, wm_ = wave_ / NWN;           // this wave's column block / row half (or phase) of the tile
-  const int ph_ = UU == 2 ? wm_ : 0, rh_ = UU == 2 ? 0 : wm_;   // output phase, row half
+  const int ph_ = UU == 2 ? wm_ % 2 : 0, rh_ = UU == 2 ? wm_ / 2 : wm_;   // output phase, row half
   const int ntap_ = a.taps.ntaps[ph_];                      // (transposed layers: 3 and 2)
   const int first = blockIdx.x * tiles_per_wg;
   int last = first + tiles_per_wg;
@@ -243,9 +247,9 @@ void sa_conv_ws_kernel(SaConvArgs a, int tiles_per_wg, int total_tiles) {
   unsigned raw_off = wave_ * 1024 + lane_ * 16;            // byte offset in the raw tile: + j*4096
   unsigned pl_off = (row0 * WS_PITCH + cq_ * 4) * 2;       // byte offset in an operand plane: + j*4*RPP*PITCH*2
   unsigned ao_off = (row0 * WS_C + cq_ * 4) * 2;           // byte offset in the a_out row block: + j*4*RPP*C*2
-  unsigned y_off = (UU == 2 ? (8 * half_ + ph_) * WS_CO + wn_ * 32 + l31_          // phase rows 2(ro + 4 half) + ph: + 2*ro*CO*4
+  unsigned y_off = (UU == 2 ? (8 * half_ + ph_ + 128 * rh_) * WS_CO + wn_ * 32 + l31_   // phase rows 2(64 rh + ro + 4 half) + ph: + 2*ro*CO*4
                             : (4 * half_ + 64 * rh_) * WS_CO + wn_ * 32 + l31_) * 4;  // byte offset in the y row block: + ro*CO*4
-  unsigned st_off = (wn_ * 32 + l31_) * 8;                 // byte offset of this lane's column in a statistics slab
+  unsigned st_off = ((G::SLABS == 2 ? rh_ * WS_CO : 0) + wn_ * 32 + l31_) * 8;   // byte offset of this lane's column in the tile's statistics slab(s)
   unsigned swap_off = (lane_ ^ 32) * 4;                    // ds_bpermute address of the lane in the other half
   asm volatile("" : "+v"(bv), "+v"(relu_floor), "+v"(row0), "+v"(dma_off), "+v"(raw_off), "+v"(pl_off), "+v"(ao_off), "+v"(y_off),
                "+v"(st_off), "+v"(swap_off));
@@ -523,7 +527,7 @@ void sa_conv_ws_kernel(SaConvArgs a, int tiles_per_wg, int total_tiles) {
       const int m = n >> 4, i = n & 15;
       const int ro = m * 32 + (i & 3) + 8 * (i >> 2);
       const float val = epi_form(n);
-      const int orow = UU == 2 ? 2 * (ro + 4 * (lane >> 5)) + ph_ : 64 * rh_ + ro + 4 * (lane >> 5);
+      const int orow = UU == 2 ? 2 * (64 * rh_ + ro + 4 * (lane >> 5)) + ph_ : 64 * rh_ + ro + 4 * (lane >> 5);
       if (T.tile * WS_TM + orow < a.Lout) {
         *reinterpret_cast<float*>(ybase_e + ro * (UU * WS_CO * 4) + y_off) = val;
         ssum += val; ssq = fmaf(val, val, ssq);
@@ -533,9 +537,12 @@ void sa_conv_ws_kernel(SaConvArgs a, int tiles_per_wg, int total_tiles) {
   // statistics of a tile: fold the two lane halves (a lane owns one column, the other half holds the
   // rows +4) and store; both halves then hold the same sums and write the same slab entry
   float st_s = 0.0f, st_q = 0.0f;
+  bool st_slab_ok = true;                                   // (two slabs per tile: does this wave's slab exist?)
   bool st_pending = false;                                  // (64 channels) partial sums wait in LDS for the tile barrier
   int st_it = 0;
   char* stbase_e = nullptr;                                 // statistics slab of the epilogue tile
+  // (two slabs per tile: the caller's slab count per utterance is that of 64-base-row tiles, possibly odd)
+  const int slab_short = G::SLABS == 2 ? 2 * a.ntiles - (((a.Lout + UU - 1) / UU + 63) / 64) : 0;
   auto epi_stats = [&](Tile T, int part = 2) {              // 0: fold the lane halves, 1: store, 2: both
     if (has_stats) {
       if (part != 1) {
@@ -543,7 +550,7 @@ void sa_conv_ws_kernel(SaConvArgs a, int tiles_per_wg, int total_tiles) {
         st_q = ssq + __int_as_float(__builtin_amdgcn_ds_bpermute((int)swap_off, __float_as_int(ssq)));
       }
       if (part != 0) {
-        if constexpr (NWM == 1) {
+        if constexpr (G::COMBINE == 1) {
           ws_store_b64(stbase_e, st_off, make_uint2(__float_as_uint(st_s), __float_as_uint(st_q)));
         } else {                                           // two row halves share a column: summed after the tile barrier
           float2* stred = reinterpret_cast<float2*>(raw + WS_RAW_BYTES) + (size_t)(st_it & 1) * 4 * 32;
@@ -556,8 +563,11 @@ void sa_conv_ws_kernel(SaConvArgs a, int tiles_per_wg, int total_tiles) {
   };
   // (64 channels) after the barrier that follows epi_stats: the waves of row half 0 add the two halves
   auto stats_out = [&]() {
-    if constexpr (NWM == 2) {
-      if (st_pending && wm_ == 0) {
+    if constexpr (G::COMBINE == 2) {
+      // (the leader of a pair: row half 0 / phase 0; its partner is NWN waves further; a transposed
+      // tile's second row half may lie wholly beyond the utterance: no slab there)
+      const bool leader = UU == 2 ? ph_ == 0 : wm_ == 0;
+      if (st_pending && leader && st_slab_ok) {
         const float2* stred = reinterpret_cast<const float2*>(raw + WS_RAW_BYTES) + (size_t)(st_it & 1) * 4 * 32;
         const float2 p0 = stred[wave_ * 32 + (lane_ & 31)], p1 = stred[(wave_ + NWN) * 32 + (lane_ & 31)];
         ws_store_b64(stbase_e, st_off, make_uint2(__float_as_uint(p0.x + p1.x), __float_as_uint(p0.y + p1.y)));
@@ -640,7 +650,8 @@ void sa_conv_ws_kernel(SaConvArgs a, int tiles_per_wg, int total_tiles) {
     if constexpr (PRO2) x2base_d = row_block(a.nb_x, Tnn.b, a.Lin, Tnn.tile * (WS_BM * WS_SA) + a.rowmin, WS_C * 4);
     aobase_t = const_cast<char*>(row_block(a.a_out, Tn.b, a.Lin, Tn.tile * (WS_BM * WS_SA) + a.rowmin, WS_C * 2));
     ybase_e = const_cast<char*>(row_block(a.y, Tp.b, a.Lout, Tp.tile * WS_TM, WS_CO * 4));
-    stbase_e = const_cast<char*>(row_block(a.stats, Tp.b, a.ntiles, Tp.tile, WS_CO * 8));
+    stbase_e = const_cast<char*>(row_block(a.stats, Tp.b, a.ntiles * G::SLABS - slab_short, Tp.tile * G::SLABS, WS_CO * 8));
+    st_slab_ok = G::SLABS == 1 || Tp.tile * 2 + rh_ < a.ntiles * 2 - slab_short;
     pl_cur = (it + 1) & 1 ? pl_off + WS_BUF_BYTES : pl_off;
     asm volatile("" : "+v"(pl_cur));
     if (doE && partialE) {
@@ -668,7 +679,7 @@ void sa_conv_ws_kernel(SaConvArgs a, int tiles_per_wg, int total_tiles) {
           // Everything up to the refill DMA of the previous tile loop has landed: vector-memory
           // operations complete in order, and behind that DMA this wave has issued exactly the 32
           // stores (+ 1 statistics store) of the slots above, which may stay in flight.
-          if (NWM == 1 && has_stats) asm volatile("s_waitcnt vmcnt(33)" ::: "memory");
+          if (G::COMBINE == 1 && has_stats) asm volatile("s_waitcnt vmcnt(33)" ::: "memory");
           else asm volatile("s_waitcnt vmcnt(32)" ::: "memory");      // (64 channels: the statistics are stored behind the barrier)
           WS_STAMP(it, 5);
           piece_read(0);
@@ -688,6 +699,15 @@ void sa_conv_ws_kernel(SaConvArgs a, int tiles_per_wg, int total_tiles) {
           if constexpr (k == 15) piece_pstat(Tn, j);
           if constexpr (k == 16) dma_piece(Tnn, false, j, 0);
           if constexpr (k == 17 && PRO2) dma_piece(Tnn, false, j, 1);
+        } else if constexpr (fs >= WS_FT && WS_SUBS == 4) {
+          // 72 slots per tile (64 -> 32 transposed): 4 slots per piece, plain rows
+          constexpr int j = (fs - WS_FT) / 4, k = (fs - WS_FT) % 4;
+          if constexpr (j > 0 && k < 2) piece_write(j - 1, k);
+          if constexpr (k == 0) { piece_level(Tn, j, 0); piece_split(j, 0); }
+          if constexpr (j + 1 < WS_DPW && k == 1) piece_read(j + 1, 0);
+          if constexpr (k == 1) piece_split(j, 1);
+          if constexpr (k == 2) { piece_split(j, 2); piece_split(j, 3); }
+          if constexpr (k == 3) { piece_cache(Tn, false, j); dma_piece(Tnn, false, j); }
         } else if constexpr (fs >= WS_FT && WS_SUBS == 6) {
           // 64 channels: a tile has 120 slots for the same transform work: 6 slots per piece = one
           // step, two dependence levels per slot (over-full on purpose: these launches are HBM-bound)
@@ -816,12 +836,13 @@ void sa_conv_ws_kernel(SaConvArgs a, int tiles_per_wg, int total_tiles) {
   {
     const bool partialE = Tp.tile * WS_TM + WS_TM > a.Lout;
     ybase_e = const_cast<char*>(row_block(a.y, Tp.b, a.Lout, Tp.tile * WS_TM, WS_CO * 4));
-    stbase_e = const_cast<char*>(row_block(a.stats, Tp.b, a.ntiles, Tp.tile, WS_CO * 8));
+    stbase_e = const_cast<char*>(row_block(a.stats, Tp.b, a.ntiles * G::SLABS - slab_short, Tp.tile * G::SLABS, WS_CO * 8));
+    st_slab_ok = G::SLABS == 1 || Tp.tile * 2 + rh_ < a.ntiles * 2 - slab_short;
     if (!partialE) eval = epi_form(0);
 #pragma unroll
     for (int n = 0; n < 32; ++n) epi_value(Tp, partialE, n);
     epi_stats(Tp);
-    if constexpr (NWM == 2) {
+    if constexpr (G::COMBINE == 2) {
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();
       stats_out();
@@ -853,7 +874,7 @@ int launch_ws(const SaConvArgs& a, hipStream_t st) {
     return -22;                                           // every input row must be staged by the tile that owns it
   if ((long)a.B * a.Lin >= (1L << 31) - 64 || (long)a.B * a.Lout >= (1L << 31) - 64) return -22;   // 32-bit row indices in the kernel
   const size_t lds = 2 * WS_BUF_BYTES + (MODE == 2 ? 2 : 1) * WS_RAW_BYTES +
-                     (MODE == 2 ? 2 * 4 * WS_C * 4 : MODE == 3 ? 2 * 4 * WS_C * 8 : G::NWM == 2 ? 2 * 4 * 32 * 8 : 0);
+                     (MODE == 2 ? 2 * 4 * WS_C * 4 : MODE == 3 ? 2 * 4 * WS_C * 8 : G::COMBINE == 2 ? 2 * 4 * 32 * 8 : 0);
   auto kern = sa_conv_ws_kernel<MODE, NT, HALO, CC, CO, SA, UU>;
   static bool attr_set = false;
   static int n_cu = 0;
@@ -879,7 +900,7 @@ int launch_ws(const SaConvArgs& a, hipStream_t st) {
 
 // Does the weight-stationary kernel serve this launch?  (sa_conv_gemm.hip asks before routing.)
 bool sa_conv_ws_covers(int dtype, int cin, int cout, int sa, int u, const SaConvArgs* a) {
-  if (dtype == SA_BF16X3 && cin == 128 && cout == 64 && sa == 1 && u == 2) {    // decoder.1: transposed, 128 -> 64
+  if (dtype == SA_BF16X3 && ((cin == 128 && cout == 64) || (cin == 64 && cout == 32)) && sa == 1 && u == 2) {   // decoder.1 / decoder.5: transposed
     if (a->taps.ntaps[0] > 3 || a->taps.ntaps[1] > 3 || a->taps.ntaps[0] < 1 || a->taps.ntaps[1] < 1) return false;
     int lo = 1 << 30, hi = -(1 << 30);
     for (int ph = 0; ph < 2; ++ph)
@@ -922,10 +943,13 @@ bool sa_conv_ws_covers(int dtype, int cin, int cout, int sa, int u, const SaConv
 }
 
 // output rows per tile (the one-tile kernel must be on the same tile height: same slab geometry)
-int sa_conv_ws_tile_rows(int cout) { return cout == 64 ? 128 : 64; }
+// tile height of the one-tile kernel this kernel's slab geometry matches, and its own output rows per tile
+int sa_conv_ws_tile_rows(int cout) { return cout == 128 ? 64 : 128; }
+int sa_conv_ws_rows_per_tile(int cout) { return cout == 128 ? 64 : cout == 64 ? 128 : 256; }
 
 int sa_conv_ws_dispatch(int cin, int cout, const SaConvArgs* a, hipStream_t st) {
   if (cin == 128 && cout == 64) return launch_ws<0, 3, 2, 128, 64, 1, 2>(*a, st);
+  if (cin == 64 && cout == 32) return launch_ws<0, 3, 2, 64, 32, 1, 2>(*a, st);
   if (cin == 64 && cout == 128) return a->s1 ? launch_ws<1, 5, 4, 64, 128, 2>(*a, st) : launch_ws<0, 5, 4, 64, 128, 2>(*a, st);
   if (cin == 64) return a->s1 ? launch_ws<1, 5, 4, 64>(*a, st) : launch_ws<0, 5, 4, 64>(*a, st);
   if (a->taps.ntaps[0] == 3) {

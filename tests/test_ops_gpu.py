@@ -859,19 +859,21 @@ def test_weight_stationary_conv_kernel_stride2(mode, Ln):
     assert rel_mse(got[0], yref) < 2e-9
 
 
-@pytest.mark.parametrize("Lin", [20160, 20003], ids=["train", "ragged"])
+@pytest.mark.parametrize("cin,cout,Lin", [(128, 64, 20160), (128, 64, 20003), (64, 32, 40320), (64, 32, 40000), (64, 32, 40003)],
+                         ids=["128-64-train", "128-64-ragged", "64-32-train", "64-32-odd-slabs", "64-32-ragged"])
 @pytest.mark.parametrize("mode", ["plain", "stats_cache"])
-def test_weight_stationary_conv_kernel_transposed(mode, Lin):
-    """decoder.1 (ConvTranspose1d 128 -> 64, k5 s2 p2 op1: models/ConvAutoEncoder.py:161-163) on the
-    weight-stationary kernel: the two waves of a column block are the two output phases (3 and 2 taps,
-    the missing tap runs zero fragments), their statistics added behind the tile barrier; output
-    bits == the one-tile kernel"""
+def test_weight_stationary_conv_kernel_transposed(mode, cin, cout, Lin):
+    """decoder.1 / decoder.5 (ConvTranspose1d 128 -> 64 and 64 -> 32, k5 s2 p2 op1:
+    models/ConvAutoEncoder.py:161-163,170-172) on the weight-stationary kernel: wave pairs of a column
+    block are the two output phases (3 and 2 taps, the missing tap runs zero fragments), their
+    statistics added behind the tile barrier; 64 -> 32: two row halves per tile = two statistics slabs
+    (an odd slab count per utterance leaves the last tile with one); output bits == the one-tile kernel"""
     from speech_anonymization_amd import _lib as L, ops
     d, B = dev(), 6
     g = torch.Generator().manual_seed(23)
-    x = torch.randn(B, Lin, 128, generator=g).to(d)
-    w = (torch.randn(128, 64, 5, generator=g) * 0.05).to(d)
-    bias = torch.randn(64, generator=g).to(d)
+    x = torch.randn(B, Lin, cin, generator=g).to(d)
+    w = (torch.randn(cin, cout, 5, generator=g) * 0.05).to(d)
+    bias = torch.randn(cout, generator=g).to(d)
     wp = ops.pack_weights(w, "convT_fwd", torch.float32, L.BF16X3)
     Lout = 2 * Lin
     kw = dict(code=L.BF16X3)
@@ -880,8 +882,8 @@ def test_weight_stationary_conv_kernel_transposed(mode, Lin):
 
     def run(ws):
         ops.conv_impl(ws=ws)
-        a_out = torch.full((B, Lin, 128), float("nan"), dtype=torch.bfloat16, device=d) if mode != "plain" else None
-        r = ops.conv_gemm(x, wp, bias, 128, 64, 1, 2, ops.UP2, Lout, a_out=a_out, **kw)
+        a_out = torch.full((B, Lin, cin), float("nan"), dtype=torch.bfloat16, device=d) if mode != "plain" else None
+        r = ops.conv_gemm(x, wp, bias, cin, cout, 1, 2, ops.UP2, Lout, a_out=a_out, **kw)
         torch.cuda.synchronize()
         return (r if isinstance(r, tuple) else (r,)) + ((a_out,) if a_out is not None else ())
 
@@ -891,12 +893,12 @@ def test_weight_stationary_conv_kernel_transposed(mode, Lin):
         a = L.SaConvArgs()
         a.B, a.Lin, a.Lout = B, Lin, Lout
         a.taps = L.make_taps(ops.UP2)
-        assert L.load().sa_conv_gemm_route(L.BF16X3, 128, 64, 1, 2, C.byref(a)) == 2
+        assert L.load().sa_conv_gemm_route(L.BF16X3, cin, cout, 1, 2, C.byref(a)) == 2
     finally:
         ops.conv_impl()
     assert torch.equal(ref[0], got[0])
     if mode != "plain":
-        assert torch.allclose(ref[1], got[1], rtol=2e-6, atol=1e-3)
+        assert ref[1].shape == got[1].shape and torch.allclose(ref[1], got[1], rtol=2e-6, atol=1e-3)
         assert not torch.isnan(got[2].float()).any() and torch.equal(ref[2], got[2])
     yref = F.conv_transpose1d(x.permute(0, 2, 1), w, bias, stride=2, padding=2, output_padding=1).permute(0, 2, 1)
     assert rel_mse(got[0], yref) < 2e-9
