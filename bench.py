@@ -323,8 +323,9 @@ def main(argv=None):
     rank, local_rank, world = sdist.ddp_init_group()
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
-    backend = torch.distributed.get_backend() if world > 1 else "none"
-    ranks_seen = torch.distributed.get_world_size() if world > 1 else 1
+    dp = sdist.dp_active()           # world > 1, or the one-rank RCCL rehearsal (SA_FORCE_DP=1)
+    backend = torch.distributed.get_backend() if dp else "none"
+    ranks_seen = torch.distributed.get_world_size() if dp else 1
     T = 1 + args.samples // 160
     T += (-T) % 36                                  # frames entering the ConvAE (padded to 36)
 

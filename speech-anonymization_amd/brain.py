@@ -443,7 +443,7 @@ class SexAnonymizationTraining(Brain):
 
     def fit_batch(self, batch):
         self.apply_epoch_schedule()
-        if (self.hip_graph and self.hparams.gradient_accumulation == 1 and sdist.world_size() == 1
+        if (self.hip_graph and self.hparams.gradient_accumulation == 1 and not sdist.dp_active()
                 and self.optimizer is not None):
             return self._fit_batch_graph(batch)
         predictions = self.compute_forward(batch, Stage.TRAIN)

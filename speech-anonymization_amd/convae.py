@@ -160,8 +160,7 @@ class ConvAutoencoder(nn.Module):
     # ---- SyncBatchNorm support: statistics sums are all-reduced across data-parallel ranks
     # (what speechbrain's Brain applies under DDP); identity on one process.
     def _bn_syncs(self):
-        import torch.distributed as dist
-        return self.sync_bn and dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+        return self.sync_bn and sdist.dp_active()
 
     def _bn_allreduce(self, sums):
         import torch.distributed as dist

@@ -25,6 +25,17 @@ def world_size():
     return dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
 
 
+def dp_active():
+    """True when the data-parallel exchanges run: an initialised process group with more than one
+    rank -- or with ONE rank under SA_FORCE_DP=1, the rehearsal that puts the real RCCL calls
+    (communicator bound to the device, ncclAvg on the side stream, SyncBatchNorm sums and counts)
+    on a one-GPU box, where every collective is the identity and the result must be bit-equal to
+    the plain single-process step (tests/test_ddp_gpu.py::test_rccl_world1_is_the_identity)."""
+    if not (dist.is_available() and dist.is_initialized()):
+        return False
+    return dist.get_world_size() > 1 or os.environ.get("SA_FORCE_DP") == "1"
+
+
 def rank():
     return dist.get_rank() if dist.is_available() and dist.is_initialized() else 0
 
@@ -48,7 +59,7 @@ def ddp_init_group(run_opts=None):
     ws = int(os.environ.get("WORLD_SIZE", "1"))
     rk = int(os.environ.get("RANK", "0"))
     lr = int(os.environ.get("LOCAL_RANK", "0"))
-    if ws > 1 and not dist.is_initialized():
+    if (ws > 1 or os.environ.get("SA_FORCE_DP") == "1") and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         backend = (run_opts.get("distributed_backend") or os.environ.get("SA_DIST_BACKEND")
@@ -109,7 +120,7 @@ class StageBuckets:
         gradient accumulation the previous micro-step's .grad must stay intact while this one is
         written (a persistent bucket would be overwritten under it)."""
         w = world_size()
-        if w == 1:
+        if not dp_active():
             return
         flat = self.flat[stage]
         if self.side is None or not flat.is_cuda:  # CPU / gloo (tests)

@@ -94,3 +94,63 @@ def test_two_ranks_equal_one_rank_with_double_batch(cuts):
         assert rel(res[0][1][k], g) < 2e-5, (k, rel(res[0][1][k], g))
     for k, v in ref_bufs.items():                                    # SyncBN: global statistics
         assert rel(res[0][2][k], v) < 1e-8, k
+
+
+def _rccl_worker(port, q):
+    """one rank, backend nccl (= RCCL): the step first without a process group, then with the
+    data-parallel exchanges forced on (SA_FORCE_DP=1)"""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1",
+                      LOCAL_RANK="0", SA_DIST_BACKEND="nccl", SA_FORCE_DP="1",
+                      HSA_ENABLE_IPC_MODE_LEGACY="0")
+    sys.path.insert(0, ROOT)
+    from oracle.convae import numpy_params
+    from speech_anonymization_amd import distributed as sdist
+    from speech_anonymization_amd.convae import ConvAutoencoder
+    torch.cuda.set_device(0)
+    feats, target, gender = _inputs(6, 72)
+    out = []
+    for dp in (False, True):
+        if dp:
+            sdist.ddp_init_group()
+            assert torch.distributed.get_backend() == "nccl" and sdist.dp_active()
+        m = ConvAutoencoder(precision="bf16x3", pooling_noise=None)
+        m.load_state_dict(numpy_params(8886))
+        m.cuda().train()
+        assert m._bn_syncs() == dp
+        for _ in range(2):                 # two steps: the second reuses allocator blocks of the first
+            for p in m.parameters():
+                p.grad = None
+            grads, bufs = _run(m, feats, target, gender)
+        out.append(({k: v.numpy() for k, v in grads.items()}, {k: v.numpy() for k, v in bufs.items()}))
+    # the collective itself, on the side stream, with RCCL's own averaging
+    side = torch.cuda.Stream()
+    x = torch.arange(1 << 20, dtype=torch.float32, device="cuda")
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        sdist.StageBuckets._average(x, 1)
+    torch.cuda.current_stream().wait_stream(side)
+    ok = bool(torch.equal(x.cpu(), torch.arange(1 << 20, dtype=torch.float32)))
+    q.put((out, ok))
+    torch.distributed.barrier()
+    torch.distributed.destroy_process_group()
+
+
+def test_rccl_world1_is_the_identity():
+    """RCCL executes: a one-rank nccl process group bound to cuda:0, the three stage buckets averaged
+    by ncclAvg on the side stream, the SyncBatchNorm sums / counts all-reduced on the main stream.
+    With one rank every collective is the identity, so gradients and BatchNorm buffers must be
+    BIT-equal to the same two steps without a process group.  (Two ranks need two GPUs: RCCL
+    refuses two ranks on one device; the two-rank arithmetic is covered over gloo above.)"""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_rccl_worker, args=(29700 + os.getpid() % 1000, q))
+    p.start()
+    (plain, dp), ok = q.get(timeout=600)
+    p.join(timeout=120)
+    assert p.exitcode == 0
+    assert ok
+    for k in plain[0]:
+        assert np.array_equal(plain[0][k], dp[0][k]), k
+    for k in plain[1]:
+        assert np.array_equal(plain[1][k], dp[1][k]), k
