@@ -324,7 +324,8 @@ def main(argv=None):
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     dp = sdist.dp_active()           # world > 1, or the one-rank RCCL rehearsal (SA_FORCE_DP=1)
-    backend = torch.distributed.get_backend() if dp else "none"
+    backend = ("sa_comm (library-owned RCCL communicator)" if sdist.lib_comm_active()
+               else torch.distributed.get_backend() if dp else "none")
     ranks_seen = torch.distributed.get_world_size() if dp else 1
     T = 1 + args.samples // 160
     T += (-T) % 36                                  # frames entering the ConvAE (padded to 36)

@@ -8,7 +8,9 @@
  *   - plain C: pointers + sizes, no torch / HIP types; `stream` is a hipStream_t passed as void*
  *     (torch.cuda.current_stream().cuda_stream); every call only ENQUEUES work on it;
  *   - every buffer (inputs, outputs, saved tensors, workspaces) is caller-allocated device
- *     memory; the library allocates nothing and keeps no state besides kernel attributes;
+ *     memory; the library allocates nothing and keeps no state besides kernel attributes --
+ *     except, per process, ONE RCCL communicator + one side stream + two events between
+ *     sa_comm_init and sa_comm_destroy (data-parallel exchange, at the end of this header);
  *   - return 0 on success, -EINVAL (-22) for bad arguments, -ENOSYS (-38) for a shape that is
  *     not instantiated, or -(hipError_t) from the launch; nothing throws across the ABI;
  *   - dtype: SA_F32 (0) or SA_BF16 (1) = storage type of activations and packed weights;
@@ -32,7 +34,9 @@ extern "C" {
                        * (SaConvArgs.wscale, undone in the epilogue); fp32 accumulation and statistics.
                        * Forward-type launches of sa_conv_gemm only (BASELINE config 5: "fp8
                        * weights/activations"); gradients stay on SA_BF16. */
+#define SA_F64 5      /* sa_comm_allreduce only: the SyncBatchNorm element counts */
 #define SA_MAX_TAPS 5
+#define SA_COMM_ID_BYTES 128
 
 /* ---- implicit-GEMM convolution (sa_conv_gemm.hip) -------------------------------------
  * Row-gather GEMM covering nn.Conv1d, nn.ConvTranspose1d(stride 2) and both data gradients
@@ -326,6 +330,27 @@ int sa_fbank_normalize(const float* feats, const float* tilemax, int B, int T, i
                        const float* lens, float top_db, int batch_max, int update, int epoch,
                        int update_until_epoch, float* state, float* scratch, float* out,
                        void* stream);
+
+/* ---- data-parallel exchange (sa_comm.hip): what DistributedDataParallel / SyncBatchNorm do for
+ * the reference once speechbrain_convae_train.py:524 (ddp_init_group) has run -- the gradient
+ * average and the BatchNorm statistic sums -- as in-place RCCL all-reduces on a side stream the
+ * library owns.  One process per GPU; rank 0 calls sa_comm_unique_id and hands the 128 bytes to
+ * the other ranks by any host channel (the Python side uses the torch.distributed store), then
+ * every rank calls sa_comm_init (collective: returns when all `world` ranks have joined).
+ *   sa_comm_allreduce: the side stream waits for everything enqueued so far on `producer_stream`,
+ *     then reduces buf[n] in place (dtype SA_F32 | SA_F64; avg != 0: ncclAvg, else sum).  Returns
+ *     at once.  sa_comm_join: `consumer_stream` waits for every all-reduce enqueued so far.
+ *   Codes: -ENOSYS no RCCL library in the process or on the loader path (it is bound by dlopen
+ *     at the first sa_comm_* call, never at load time), -ENOTCONN before sa_comm_init, -EEXIST
+ *     second sa_comm_init, -(1000 + ncclResult_t) from RCCL, -(hipError_t) from HIP.
+ *   sa_comm_world: 0 before init.  sa_comm_ncalls: all-reduces enqueued since init (tests). */
+int sa_comm_unique_id(void* id128);
+int sa_comm_init(int rank, int world, const void* id128, int device);
+int sa_comm_world(void);
+int sa_comm_allreduce(void* buf, long long n, int dtype, int avg, void* producer_stream);
+int sa_comm_join(void* consumer_stream);
+int sa_comm_ncalls(void);
+int sa_comm_destroy(void);
 
 #ifdef __cplusplus
 }

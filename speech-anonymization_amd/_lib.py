@@ -12,7 +12,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # SA_HIP_LIB points the binding at another build of the same ABI (kernel A/B experiments)
 LIB_PATH = os.environ.get("SA_HIP_LIB") or os.path.join(_HERE, "libsa_hip.so")
 
-F32, BF16, BF16X3, BF16X1F, FP8 = 0, 1, 2, 3, 4
+F32, BF16, BF16X3, BF16X1F, FP8, F64 = 0, 1, 2, 3, 4, 5
 MAX_TAPS = 5
 
 c_fp = C.POINTER(C.c_float)
@@ -87,6 +87,8 @@ SYMBOLS = [
     "sa_loss_workspace_bytes", "sa_recon_loss", "sa_cls_losses", "sa_cosine_loss",
     "sa_tdnn_fwd", "sa_time_pool", "sa_leaky_affine", "sa_tdnn_bwd_input", "sa_tdnn_fold", "sa_time_pool_bwd",
     "sa_leaky_affine_bwd", "sa_cluster_mi", "sa_fbank", "sa_fbank_table_elems", "sa_fbank_ntiles", "sa_fbank_scratch_bytes", "sa_fbank_normalize",
+    "sa_comm_unique_id", "sa_comm_init", "sa_comm_world", "sa_comm_allreduce", "sa_comm_join", "sa_comm_ncalls",
+    "sa_comm_destroy",
 ]
 
 _lib = None

@@ -163,10 +163,9 @@ class ConvAutoencoder(nn.Module):
         return self.sync_bn and sdist.dp_active()
 
     def _bn_allreduce(self, sums):
-        import torch.distributed as dist
         if self._bn_syncs():
-            dist.all_reduce(sums)
-            return dist.get_world_size()
+            sdist.all_reduce_now(sums)
+            return sdist.world_size()
         return 1
 
     def _bn_global_counts(self, counts, device):
@@ -178,7 +177,6 @@ class ConvAutoencoder(nn.Module):
         sa_fin_bn_fwd / sa_fin_norm_bwd / sa_bn2d_bwd `count_dev`).  None on a single process."""
         if not self._bn_syncs():
             return None
-        import torch.distributed as dist
         key = (tuple(counts), str(device))
         cache = self.__dict__.setdefault("_count_cache", {})
         local = cache.get(key)
@@ -187,7 +185,7 @@ class ConvAutoencoder(nn.Module):
                 cache.clear()
             local = cache[key] = torch.tensor(counts, dtype=torch.float64).to(device)
         g = local.clone()
-        dist.all_reduce(g)
+        sdist.all_reduce_now(g)
         return g
 
     def _bn_rows(self):

@@ -10,6 +10,12 @@ the backward kernels straight into three flat fp32 stage buckets (classifier 0.8
 0.62 MB, encoder 0.62 MB, in completion order); each bucket is all-reduced on a SIDE stream as soon as its stage is
 complete, so the collective (latency-bound at this size) overlaps the rest of backward, and the
 main stream joins the side stream once, before the optimizer touches the gradients.
+
+Two carriers for the same exchanges: torch.distributed's "nccl" backend (RCCL; the default) or the
+library's own communicator (`SA_COMM=lib` / run_opts["comm"] = "lib": csrc/sa_comm.hip,
+include/sa_hip.h "data-parallel exchange" -- SURVEY 8b's sa_comm_init / sa_comm_destroy), which
+owns its side stream and events; torch.distributed is then only the rendezvous that carries the
+128-byte RCCL id (gloo by default, so that the process holds ONE RCCL communicator).
 """
 import os
 
@@ -34,6 +40,53 @@ def dp_active():
     if not (dist.is_available() and dist.is_initialized()):
         return False
     return dist.get_world_size() > 1 or os.environ.get("SA_FORCE_DP") == "1"
+
+
+def lib_comm_active():
+    """the library-owned RCCL communicator is up (sa_comm_init has run in this process)"""
+    from . import _lib as L
+    return L._lib is not None and L._lib.sa_comm_world() > 0
+
+
+def lib_comm_init(device_index):
+    """sa_comm_unique_id on rank 0 -> the 128 bytes travel through the torch.distributed group ->
+    sa_comm_init on every rank (collective)."""
+    import ctypes as C
+    from . import _lib as L
+    lib = L.load()
+    ident = C.create_string_buffer(128)
+    if dist.get_rank() == 0:
+        L.check(lib.sa_comm_unique_id(ident), "sa_comm_unique_id")
+    box = [ident.raw]
+    if dist.get_world_size() > 1:
+        dist.broadcast_object_list(box, src=0)
+    L.check(lib.sa_comm_init(dist.get_rank(), dist.get_world_size(), box[0], int(device_index)),
+            "sa_comm_init")
+
+
+def lib_comm_destroy():
+    from . import _lib as L
+    if lib_comm_active():
+        L.check(L._lib.sa_comm_destroy(), "sa_comm_destroy")
+
+
+def _lib_allreduce(t, avg):
+    import ctypes as C
+    from . import _lib as L
+    code = {torch.float32: L.F32, torch.float64: L.F64}[t.dtype]
+    L.check(L._lib.sa_comm_allreduce(L.ptr(t), C.c_longlong(t.numel()), code, int(avg), L.stream()),
+            "sa_comm_allreduce")
+
+
+def all_reduce_now(t):
+    """in-place SUM whose result the next kernel on the current stream consumes (the BatchNorm
+    statistic sums and counts): on the library communicator the current stream joins at once"""
+    if lib_comm_active() and t.is_cuda:
+        from . import _lib as L
+        _lib_allreduce(t, False)
+        L.check(L._lib.sa_comm_join(L.stream()), "sa_comm_join")
+    else:
+        dist.all_reduce(t)
 
 
 def rank():
@@ -62,8 +115,9 @@ def ddp_init_group(run_opts=None):
     if (ws > 1 or os.environ.get("SA_FORCE_DP") == "1") and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
+        use_lib = (run_opts.get("comm") or os.environ.get("SA_COMM", "torch")) == "lib"
         backend = (run_opts.get("distributed_backend") or os.environ.get("SA_DIST_BACKEND")
-                   or ("nccl" if torch.cuda.is_available() else "gloo"))
+                   or ("nccl" if torch.cuda.is_available() and not use_lib else "gloo"))
         if os.environ.get("SA_SAME_DEVICE") == "1":   # rehearsal: several ranks share GPU 0 (gloo only)
             lr = 0
         if backend == "nccl":
@@ -72,6 +126,9 @@ def ddp_init_group(run_opts=None):
                                     device_id=torch.device("cuda", lr))
         else:
             dist.init_process_group(backend, rank=rk, world_size=ws)
+        if use_lib:
+            torch.cuda.set_device(lr)
+            lib_comm_init(lr)
     return rk, lr, ws
 
 
@@ -123,6 +180,12 @@ class StageBuckets:
         if not dp_active():
             return
         flat = self.flat[stage]
+        if flat.is_cuda and lib_comm_active():
+            # library communicator: its own side stream waits for this stream's work so far; the
+            # bucket stays referenced (.grad views) until after join(), so no record_stream
+            _lib_allreduce(flat, True)
+            self.pending = "lib"
+            return
         if self.side is None or not flat.is_cuda:  # CPU / gloo (tests)
             self._average(flat, w)
             return
@@ -135,6 +198,9 @@ class StageBuckets:
         self.pending = True
 
     def join(self):
-        if self.pending:
+        if self.pending == "lib":
+            from . import _lib as L
+            L.check(L._lib.sa_comm_join(L.stream()), "sa_comm_join")
+        elif self.pending:
             torch.cuda.current_stream().wait_stream(self.side)
-            self.pending = False
+        self.pending = False

@@ -44,6 +44,20 @@ def test_ctypes_structs_match_header_field_order():
         assert names == [f[0] for f in st._fields_], st.__name__
 
 
+def test_comm_entry_points_before_init():
+    """the data-parallel exchange entry points (sa_comm_init / sa_comm_destroy) without a
+    communicator: no RCCL, no HIP call is reached -- the codes include/sa_hip.h documents"""
+    import errno
+    from speech_anonymization_amd import _lib
+    lib = _lib.load()
+    assert lib.sa_comm_world() == 0
+    assert lib.sa_comm_allreduce(None, ctypes.c_longlong(4), _lib.F32, 1, None) == -errno.ENOTCONN
+    assert lib.sa_comm_join(None) == -errno.ENOTCONN
+    assert lib.sa_comm_init(0, 1, None, 0) == -errno.EINVAL
+    assert lib.sa_comm_init(2, 2, b"x" * 128, 0) == -errno.EINVAL
+    assert lib.sa_comm_destroy() == 0
+
+
 def test_missing_library_fails_loudly(monkeypatch):
     from speech_anonymization_amd import _lib
     monkeypatch.setattr(_lib, "_lib", None)

@@ -96,12 +96,16 @@ def test_two_ranks_equal_one_rank_with_double_batch(cuts):
         assert rel(res[0][2][k], v) < 1e-8, k
 
 
-def _rccl_worker(port, q):
-    """one rank, backend nccl (= RCCL): the step first without a process group, then with the
-    data-parallel exchanges forced on (SA_FORCE_DP=1)"""
+def _rccl_worker(port, q, carrier):
+    """one rank on RCCL: the step first without a process group, then with the data-parallel
+    exchanges forced on (SA_FORCE_DP=1).  carrier "torch": torch.distributed's nccl backend;
+    "lib": the library's own communicator (sa_comm_*), torch.distributed (gloo) only as rendezvous"""
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1",
-                      LOCAL_RANK="0", SA_DIST_BACKEND="nccl", SA_FORCE_DP="1",
-                      HSA_ENABLE_IPC_MODE_LEGACY="0")
+                      LOCAL_RANK="0", SA_FORCE_DP="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    if carrier == "lib":
+        os.environ["SA_COMM"] = "lib"
+    else:
+        os.environ["SA_DIST_BACKEND"] = "nccl"
     sys.path.insert(0, ROOT)
     from oracle.convae import numpy_params
     from speech_anonymization_amd import distributed as sdist
@@ -112,7 +116,9 @@ def _rccl_worker(port, q):
     for dp in (False, True):
         if dp:
             sdist.ddp_init_group()
-            assert torch.distributed.get_backend() == "nccl" and sdist.dp_active()
+            assert sdist.dp_active()
+            assert torch.distributed.get_backend() == ("gloo" if carrier == "lib" else "nccl")
+            assert sdist.lib_comm_active() == (carrier == "lib")
         m = ConvAutoencoder(precision="bf16x3", pooling_noise=None)
         m.load_state_dict(numpy_params(8886))
         m.cuda().train()
@@ -126,27 +132,45 @@ def _rccl_worker(port, q):
     side = torch.cuda.Stream()
     x = torch.arange(1 << 20, dtype=torch.float32, device="cuda")
     side.wait_stream(torch.cuda.current_stream())
-    with torch.cuda.stream(side):
-        sdist.StageBuckets._average(x, 1)
-    torch.cuda.current_stream().wait_stream(side)
+    ncalls = -1
+    if carrier == "lib":
+        from speech_anonymization_amd import _lib as L
+        ncalls = L._lib.sa_comm_ncalls()
+        b = sdist.StageBuckets([("encoder.w", x)], x.device)
+        b.flat["encoder"].copy_(x)
+        b.reduce_stage("encoder")
+        b.join()
+        x = b.flat["encoder"]
+    else:
+        with torch.cuda.stream(side):
+            sdist.StageBuckets._average(x, 1)
+        torch.cuda.current_stream().wait_stream(side)
     ok = bool(torch.equal(x.cpu(), torch.arange(1 << 20, dtype=torch.float32)))
-    q.put((out, ok))
+    q.put((out, ok, ncalls))
     torch.distributed.barrier()
+    if carrier == "lib":
+        sdist.lib_comm_destroy()
+        assert not sdist.lib_comm_active()
     torch.distributed.destroy_process_group()
 
 
-def test_rccl_world1_is_the_identity():
-    """RCCL executes: a one-rank nccl process group bound to cuda:0, the three stage buckets averaged
-    by ncclAvg on the side stream, the SyncBatchNorm sums / counts all-reduced on the main stream.
+@pytest.mark.parametrize("carrier", ["torch", "lib"])
+def test_rccl_world1_is_the_identity(carrier):
+    """RCCL executes: a one-rank communicator bound to cuda:0 (torch.distributed's nccl backend, or
+    the library's own through sa_comm_init), the three stage buckets averaged by ncclAvg on the side
+    stream, the SyncBatchNorm sums / counts all-reduced for the main stream.
     With one rank every collective is the identity, so gradients and BatchNorm buffers must be
     BIT-equal to the same two steps without a process group.  (Two ranks need two GPUs: RCCL
     refuses two ranks on one device; the two-rank arithmetic is covered over gloo above.)"""
     import torch.multiprocessing as mp
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    p = ctx.Process(target=_rccl_worker, args=(29700 + os.getpid() % 1000, q))
+    p = ctx.Process(target=_rccl_worker, args=(29700 + os.getpid() % 1000 + (carrier == "lib"), q, carrier))
     p.start()
-    (plain, dp), ok = q.get(timeout=600)
+    (plain, dp), ok, ncalls = q.get(timeout=600)
+    if carrier == "lib":
+        # two steps x (3 stage buckets + the SyncBatchNorm exchanges of one step)
+        assert ncalls >= 2 * (3 + 6), ncalls
     p.join(timeout=120)
     assert p.exitcode == 0
     assert ok
