@@ -339,7 +339,8 @@ int sa_fbank_normalize(const float* feats, const float* tilemax, int B, int T, i
  * every rank calls sa_comm_init (collective: returns when all `world` ranks have joined).
  *   sa_comm_allreduce: the side stream waits for everything enqueued so far on `producer_stream`,
  *     then reduces buf[n] in place (dtype SA_F32 | SA_F64; avg != 0: ncclAvg, else sum).  Returns
- *     at once.  sa_comm_join: `consumer_stream` waits for every all-reduce enqueued so far.
+ *     at once.  sa_comm_allreduce_inline: the same collective enqueued in `stream` itself (no side
+ *     stream, no events: producer and consumer are that stream's neighbours).  sa_comm_join: `consumer_stream` waits for every all-reduce enqueued so far.
  *   Codes: -ENOSYS no RCCL library in the process or on the loader path (it is bound by dlopen
  *     at the first sa_comm_* call, never at load time), -ENOTCONN before sa_comm_init, -EEXIST
  *     second sa_comm_init, -(1000 + ncclResult_t) from RCCL, -(hipError_t) from HIP.
@@ -348,6 +349,7 @@ int sa_comm_unique_id(void* id128);
 int sa_comm_init(int rank, int world, const void* id128, int device);
 int sa_comm_world(void);
 int sa_comm_allreduce(void* buf, long long n, int dtype, int avg, void* producer_stream);
+int sa_comm_allreduce_inline(void* buf, long long n, int dtype, int avg, void* stream);
 int sa_comm_join(void* consumer_stream);
 int sa_comm_ncalls(void);
 int sa_comm_destroy(void);

@@ -87,7 +87,7 @@ SYMBOLS = [
     "sa_loss_workspace_bytes", "sa_recon_loss", "sa_cls_losses", "sa_cosine_loss",
     "sa_tdnn_fwd", "sa_time_pool", "sa_leaky_affine", "sa_tdnn_bwd_input", "sa_tdnn_fold", "sa_time_pool_bwd",
     "sa_leaky_affine_bwd", "sa_cluster_mi", "sa_fbank", "sa_fbank_table_elems", "sa_fbank_ntiles", "sa_fbank_scratch_bytes", "sa_fbank_normalize",
-    "sa_comm_unique_id", "sa_comm_init", "sa_comm_world", "sa_comm_allreduce", "sa_comm_join", "sa_comm_ncalls",
+    "sa_comm_unique_id", "sa_comm_init", "sa_comm_world", "sa_comm_allreduce", "sa_comm_allreduce_inline", "sa_comm_join", "sa_comm_ncalls",
     "sa_comm_destroy",
 ]
 

@@ -9,9 +9,12 @@
 //   sa_comm_allreduce(buf, ..., producer):  record ev_in on `producer`, side waits ev_in,
 //       ncclAllReduce in place on the side stream.  Returns at once; the producer stream goes on
 //       with the rest of backward while the collective (latency-bound at 0.6-0.9 MB) runs.
+//   sa_comm_allreduce_inline(buf, ..., stream):  the collective in `stream` itself, no event hop:
+//       for the BatchNorm statistic sums, whose producer is the previous kernel and whose consumer
+//       the next one (measured on one rank: two event hops per exchange cost ~35 us of bubble
+//       each, twelve times per step).
 //   sa_comm_join(consumer):                 record ev_out on side, `consumer` waits ev_out.
-//       Called once before the optimizer reads the gradients (or right away for the BatchNorm
-//       sums, whose consumer is the next kernel).
+//       Called once per backward, before the optimizer reads the gradients.
 // RCCL is bound at run time (dlopen "librccl.so.1"): the process usually holds torch's copy
 // already, and two copies of RCCL in one process must not happen; the library has no link-time
 // dependency on it, and single-process use never touches it.
@@ -124,6 +127,18 @@ int sa_comm_allreduce(void* buf, long long n, int dtype, int avg, void* producer
   g_comm.ncalls++;
   return nccl_rc(g_rccl.AllReduce(buf, buf, (size_t)n, dt, avg ? ncclAvg : ncclSum, g_comm.comm,
                                   g_comm.side));
+}
+
+int sa_comm_allreduce_inline(void* buf, long long n, int dtype, int avg, void* stream) {
+  if (!g_comm.comm) return -ENOTCONN;
+  if (!buf || n <= 0) return -EINVAL;
+  ncclDataType_t dt;
+  if (dtype == SA_F32) dt = ncclFloat32;
+  else if (dtype == SA_F64) dt = ncclFloat64;
+  else return -EINVAL;
+  g_comm.ncalls++;
+  return nccl_rc(g_rccl.AllReduce(buf, buf, (size_t)n, dt, avg ? ncclAvg : ncclSum, g_comm.comm,
+                                  (hipStream_t)stream));
 }
 
 int sa_comm_join(void* consumer_stream) {

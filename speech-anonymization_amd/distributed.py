@@ -70,21 +70,20 @@ def lib_comm_destroy():
         L.check(L._lib.sa_comm_destroy(), "sa_comm_destroy")
 
 
-def _lib_allreduce(t, avg):
+def _lib_allreduce(t, avg, inline=False):
     import ctypes as C
     from . import _lib as L
     code = {torch.float32: L.F32, torch.float64: L.F64}[t.dtype]
-    L.check(L._lib.sa_comm_allreduce(L.ptr(t), C.c_longlong(t.numel()), code, int(avg), L.stream()),
-            "sa_comm_allreduce")
+    fn = L._lib.sa_comm_allreduce_inline if inline else L._lib.sa_comm_allreduce
+    L.check(fn(L.ptr(t), C.c_longlong(t.numel()), code, int(avg), L.stream()), "sa_comm_allreduce")
 
 
 def all_reduce_now(t):
     """in-place SUM whose result the next kernel on the current stream consumes (the BatchNorm
-    statistic sums and counts): on the library communicator the current stream joins at once"""
+    statistic sums and counts): on the library communicator the collective is enqueued in the
+    current stream itself -- no side stream, no event hop"""
     if lib_comm_active() and t.is_cuda:
-        from . import _lib as L
-        _lib_allreduce(t, False)
-        L.check(L._lib.sa_comm_join(L.stream()), "sa_comm_join")
+        _lib_allreduce(t, False, inline=True)
     else:
         dist.all_reduce(t)
 

@@ -52,6 +52,7 @@ def test_comm_entry_points_before_init():
     lib = _lib.load()
     assert lib.sa_comm_world() == 0
     assert lib.sa_comm_allreduce(None, ctypes.c_longlong(4), _lib.F32, 1, None) == -errno.ENOTCONN
+    assert lib.sa_comm_allreduce_inline(None, ctypes.c_longlong(4), _lib.F32, 0, None) == -errno.ENOTCONN
     assert lib.sa_comm_join(None) == -errno.ENOTCONN
     assert lib.sa_comm_init(0, 1, None, 0) == -errno.EINVAL
     assert lib.sa_comm_init(2, 2, b"x" * 128, 0) == -errno.EINVAL
