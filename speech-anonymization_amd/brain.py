@@ -281,8 +281,10 @@ class Brain:
 
 
 class SexAnonymizationTraining(Brain):
-    """The reference's Brain subclass for model_type convae / endtoend (ASR utility loss and the
-    external-classifier evaluation are out of scope of this path: SURVEY.md 8f)."""
+    """The reference's Brain subclass for model_type convae / endtoend.  `self.asr_brain` (an
+    asr.ASR, attached like speechbrain_convae_train.py:560-574 attaches the pretrained recogniser)
+    switches the frozen-ASR utility loss on (SURVEY.md 8f-2: throughput-only, parity unpinned);
+    without it the term is 0, whatever utility_loss_weight says."""
 
     def features(self, wavs, wav_lens):
         feats = self.hparams.compute_features(wavs)
@@ -306,6 +308,12 @@ class SexAnonymizationTraining(Brain):
         feats = self.features(wavs, wav_lens)          # the reference recomputes the targets (:82-87)
         hp = self.hparams
         utility_loss = 0.0
+        asr_brain = getattr(self, "asr_brain", None)
+        if stage == Stage.TRAIN and hp.utility_loss_weight > 0 and asr_brain is not None:
+            from . import asr                                   # reference :97-102
+            tokens_bos, _ = batch.tokens_bos
+            utility_loss = asr.utility_loss(asr_brain, hp.loss_utility, feats, reconstructed_speech,
+                                            wav_lens, tokens_bos, batch)
         B = reconstructed_speech.shape[0]
         recon_loss = hp.loss_reconstruction(reconstructed_speech.view(B, -1), feats.view(B, -1))
         sex_loss = hp.loss_sex_classification(sex_logits, sex_label)

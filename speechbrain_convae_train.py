@@ -53,6 +53,18 @@ def main(argv):
     model = model.to(sa_brain.device)
     sa_brain.modules["ConvAE"] = model
     hparams["model"].append(sa_brain.modules["ConvAE"])      # ModuleList index 0 (reference :580)
+    if hparams.get("asr_utility"):
+        # reference :560-574 attaches the pretrained recogniser as sa_brain.asr_brain; its weights
+        # are a hub fetch, so here `--asr_utility random` builds the same architecture with random
+        # frozen weights (throughput-only) and a path loads this module's own state_dict
+        from speech_anonymization_amd import asr
+        rec = asr.ASR(dtype=torch.bfloat16 if sa_brain.device.type == "cuda" else None)
+        if hparams["asr_utility"] != "random":
+            rec.load_state_dict(torch.load(hparams["asr_utility"], map_location="cpu", weights_only=True))
+        sa_brain.asr_brain = rec.to(sa_brain.device)
+        if not hasattr(sa_brain.hparams, "loss_utility"):
+            from speech_anonymization_amd import losses
+            sa_brain.hparams.loss_utility = losses.CosineSimilarityLoss()
 
     bs = hparams["batch_size"]
     if synthetic:

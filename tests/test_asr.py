@@ -1,0 +1,144 @@
+"""Frozen-ASR utility branch: PARITY UNPINNED -- speechbrain's TransformerASR /
+ConvolutionFrontEnd are not in the reference tree and the weights are a hub fetch, so there is
+nothing to compare numbers with.  These are the properties the architecture implies
+(speechbrain_configs/convae.yaml:139-182; models/SpeechBrain_ASR.py:16-30,101-103; call sites
+speechbrain_convae_train.py:97-102)."""
+import pytest
+import torch
+
+from speech_anonymization_amd import asr as A
+
+
+def _small(dtype=torch.float32):
+    cnn = A.ConvolutionFrontEnd(out_channels=(8, 16, 32))
+    tr = A.TransformerASR(input_size=cnn.out_features, tgt_vocab=50, d_model=64, nhead=4,
+                          num_encoder_layers=2, num_decoder_layers=2, d_ffn=128)
+    return A.ASR(cnn, tr, output_neurons=50, dtype=dtype)
+
+
+def test_parameter_count_of_the_reference_configuration():
+    """convae.yaml:139-182: CNN + Transformer + seq_lin + ctc_lin = 161.6 M"""
+    with torch.device("meta"):
+        m = A.ASR()
+    n = sum(p.numel() for p in m.parameters())
+    assert abs(n - 161.6e6) < 0.3e6, n
+    assert not any(p.requires_grad for p in m.parameters())
+    assert m.CNN.out_features == 10240                           # Transformer input_size in the YAML
+
+
+def test_shapes_masks_and_causality():
+    torch.manual_seed(0)
+    m = _small()
+    B, T, U = 3, 72, 7
+    feats = torch.randn(B, T, 80)
+    lens = torch.tensor([1.0, 0.5, 0.75])
+    tok = torch.randint(3, 50, (B, U))
+    tok[:, 0] = 1
+    tok[2, 5:] = 0                                               # padding
+    enc, pred = m.get_predictions(feats, lens, tok, eval=True)
+    assert enc.shape == (B, T // 4, 64) and pred.shape == (B, U, 64)
+    assert torch.isfinite(enc).all() and torch.isfinite(pred).all()
+    # decoder is causal: changing token u changes nothing before u
+    tok2 = tok.clone()
+    tok2[:, 4] = (tok2[:, 4] + 7) % 47 + 3
+    _, pred2 = m.get_predictions(feats, lens, tok2, eval=True)
+    assert torch.allclose(pred[:, :4], pred2[:, :4], atol=1e-6)
+    assert not torch.allclose(pred[:, 4:], pred2[:, 4:], atol=1e-6)
+    # encoder key-padding mask: encoder states of utterance 1 beyond its length do not reach its
+    # valid positions through attention -- perturb the transformer input there, not the features
+    # (the CNN's receptive field straddles the boundary)
+    src = m.CNN(feats)
+    src2 = src.clone()
+    src2[1, (T // 4) // 2 + 1:] += 1.0
+    e1, _ = m.Transformer(src, tok, lens)
+    e2, _ = m.Transformer(src2, tok, lens)
+    n1 = (T // 4) // 2
+    assert torch.allclose(e1[1, :n1], e2[1, :n1], atol=1e-6)
+    assert torch.allclose(e1[0], e2[0], atol=1e-6)
+
+
+def test_gradient_reaches_the_reconstruction_only():
+    torch.manual_seed(1)
+    m = _small()
+
+    class Cos(torch.nn.Module):                                  # the arithmetic of utils/cosine_similarity_loss.py:53-56
+        def forward(self, a, b):
+            l = 1 - torch.nn.functional.cosine_similarity(a, b, dim=2, eps=1e-6)
+            return l.sum() / l.shape[1]
+    B, T, U = 2, 36, 5
+    feats = torch.randn(B, T, 80)
+    recon = (feats + 0.1 * torch.randn(B, T, 80)).requires_grad_()
+    tok = torch.randint(3, 50, (B, U))
+    tok[:, 0] = 1
+    lens = torch.ones(B)
+    loss = A.utility_loss(m, Cos(), feats, recon, lens, tok)
+    loss.backward()
+    assert recon.grad is not None and float(recon.grad.abs().sum()) > 0
+    assert all(p.grad is None for p in m.parameters())
+    assert float(loss) > 0
+    same = A.utility_loss(m, Cos(), feats, feats.clone().requires_grad_(), lens, tok)
+    assert abs(float(same)) < 1e-5                               # identical inputs: zero loss
+    m.train()
+    assert not m.training                                        # frozen recogniser stays in eval mode
+    with pytest.raises(NotImplementedError):
+        m.get_predictions(feats, lens, tok, do_ctc=True)
+
+
+@pytest.mark.gpu
+def test_utility_loss_in_the_train_step_on_gpu():
+    """the branch inside compute_objectives with the library's sa_cosine_loss as loss_utility: bf16
+    recogniser against the same weights in fp32 (loss within 5 %; 1 - cos cancels, so the
+    perturbation is large), gradient direction the same"""
+    from speech_anonymization_amd.losses import CosineSimilarityLoss
+    torch.manual_seed(2)
+    m32 = _small().cuda()
+    m16 = _small(torch.bfloat16).cuda()
+    B, T, U = 4, 72, 6
+    feats = torch.randn(B, T, 80, device="cuda")
+    tok = torch.randint(3, 50, (B, U), device="cuda")
+    tok[:, 0] = 1
+    lens = torch.ones(B, device="cuda")
+    out = []
+    for m in (m32, m16):
+        recon = (feats + 1.5 * torch.sin(7 * feats)).requires_grad_()
+        loss = A.utility_loss(m, CosineSimilarityLoss(), feats, recon, lens, tok)
+        loss.backward()
+        out.append((float(loss), recon.grad.clone()))
+    assert out[0][0] > 0.01 and abs(out[1][0] - out[0][0]) < 0.05 * out[0][0], (out[0][0], out[1][0])
+    g32, g16 = out[0][1], out[1][1]
+    cos = float((g32 * g16).sum() / (g32.norm() * g16.norm()))
+    assert cos > 0.95, cos
+
+
+@pytest.mark.gpu
+def test_brain_adds_the_utility_term():
+    """compute_objectives with an attached recogniser (speechbrain_convae_train.py:97-102,122-128):
+    loss = 0.1 recon + 0.9 sex + w * utility, and the utility gradient reaches the decoder"""
+    import bench
+    from speech_anonymization_amd.brain import Stage
+    from speech_anonymization_amd.losses import CosineSimilarityLoss
+    dev = torch.device("cuda", 0)
+    brain = bench.build_brain(dev, "bf16x3", 2)
+    batch = bench.synthetic_batch(2, 0, dev, n_samples=36 * 160 * 2 - 160)
+    tok = torch.randint(3, 50, (2, 5), device=dev)
+    tok[:, 0] = 1
+    batch.tokens_bos = (tok, torch.ones(2, device=dev))
+    brain.hparams.loss_utility = CosineSimilarityLoss()
+    brain.modules.ConvAE.pooling_noise = None
+    brain.hparams.epoch_counter.current = 10         # past update_until_epoch: the normaliser is frozen
+    torch.manual_seed(3)
+    base = brain.compute_objectives(brain.compute_forward(batch, Stage.TRAIN), batch, Stage.TRAIN)
+    brain.asr_brain = _small(torch.bfloat16).to(dev)
+    brain.hparams.utility_loss_weight = 0.5
+    pred = brain.compute_forward(batch, Stage.TRAIN)
+    with_u = brain.compute_objectives(pred, batch, Stage.TRAIN)
+    from speech_anonymization_amd import asr as A2
+    feats = brain.features(*batch.sig)
+    u = A2.utility_loss(brain.asr_brain, brain.hparams.loss_utility, feats, pred[0].detach(),
+                        batch.sig[1], tok)
+    assert float(u) > 0
+    assert abs(float(with_u) - float(base) - 0.5 * float(u)) < 2e-3 * abs(float(with_u)) + 1e-4
+    with_u.backward()
+    g = brain.modules.ConvAE.decoder[8].weight.grad if hasattr(brain.modules.ConvAE, "decoder") else None
+    assert g is None or torch.isfinite(g).all()
+    assert any(p.grad is not None and float(p.grad.abs().sum()) > 0 for p in brain.modules.ConvAE.parameters())
