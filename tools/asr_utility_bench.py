@@ -69,6 +69,21 @@ def main():
     brain.asr_brain = m
     brain.hparams.utility_loss_weight = 0.2
     ms_with = timed(lambda: brain.fit_batch(batch), args.steps)
+    # the same step as a hipGraph replay (run_opts hip_graph): the frozen branch is ~1 500 launches
+    # of <= 30 us, i.e. host-issue-bound when launched eagerly
+    ms_graph = None
+    try:
+        gb = bench.build_brain(dev, "bf16x3", B, hip_graph=True)
+        gb.hparams.loss_utility = cos
+        gb.asr_brain = m
+        gb.hparams.utility_loss_weight = 0.2
+
+        def gstep():
+            gb.step += 1
+            gb.fit_batch(batch)
+        ms_graph = timed(gstep, args.steps, warmup=6)
+    except Exception as e:                                      # capture is best-effort here
+        print(f"graph replay failed: {type(e).__name__}: {e}", file=sys.stderr)
     print(json.dumps({
         "what": "frozen-ASR utility branch, random-init reference architecture (parity unpinned)",
         "params": nparam, "batch": B, "frames_per_utt": T, "target_tokens": U, "dtype": "bf16 (fp32 accumulate)",
@@ -76,6 +91,8 @@ def main():
         "branch_frames_per_s": B * T / ms_branch * 1e3,
         "convae_step_ms": ms_plain, "convae_step_with_utility_ms": ms_with,
         "frames_per_s_with_utility": B * T / ms_with * 1e3,
+        "convae_step_with_utility_graph_replay_ms": ms_graph,
+        "frames_per_s_with_utility_graph_replay": (B * T / ms_graph * 1e3) if ms_graph else None,
         "hbm_allocated_gb": torch.cuda.max_memory_allocated() / 1e9}))
 
 
