@@ -6,7 +6,7 @@ TAG=${1:-r02}
 OUT=$PWD/gpurun_out/$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
-B="--no-cpu-baseline --no-b10"
+B="--no-cpu-baseline --no-b10 --no-graph"   # eager only: under the profiler the host is slow enough to trigger the replay re-timing
 run() { name=$1; shift; echo "== $name: $*"; ( cd $PWD && timeout -k 10 420 rocprofv3 "$@" ) > $OUT/$name.log 2>&1; echo "   rc=$?"; }
 run ks  --kernel-trace --stats --output-format csv -d /tmp/prof_ks -o ks -- python3 bench.py --steps 5 --warmup 2 $B
 run fetch --pmc FETCH_SIZE --output-format csv -d /tmp/prof_fetch -o fetch -- python3 bench.py --steps 2 --warmup 0 $B
