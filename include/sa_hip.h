@@ -266,8 +266,10 @@ int sa_pool_bwd(int dtype, const void* r, const float* scale, const float* shift
 int sa_dense(const float* X, int lda, const float* ps, const float* pt, const float* W, int sbk,
              int sbn, const float* bias, float* Y, int ldy, int M, int N, int K, int relu,
              void* stream);
+/* out0 / out1 (either may be NULL): sums[n][0] / sums[n][1] rounded to fp32, written straight into a
+ * parameter-gradient tensor (the bias / BatchNorm affine gradients of the FC head) */
 int sa_colsums(const float* X, const float* H, const float* hmean, const float* hrstd, int M, int N,
-               double* sums, void* stream);
+               double* sums, float* out0, float* out1, void* stream);
 int sa_bn2d_bwd(const float* G, const float* H, const double* sums, double count, const float* gamma,
                 const float* mean, const float* rstd, int relu_mask, int M, int N, float* dH,
                 const double* count_dev, void* stream);

@@ -624,19 +624,21 @@ class _ConvAEFn(torch.autograd.Function):
             dLG = ops.log_softmax_bwd(d_logp.contiguous().float(), S["logp"])
             H1, H2 = S["H1"], S["H2"]
             G[c + "6.weight"] = ops.dense_wgrad(dLG, H2, newg(c + "6.weight"), ps=f2[2], pt=f2[3])
-            setg(c + "6.bias", ops.colsums(dLG)[:, 0])
+            G[c + "6.bias"] = newg(c + "6.bias"); ops.colsums(dLG, out0=G[c + "6.bias"])
             dN2 = ops.dense(dLG, P[c + "6.weight"], None, 64, 2, transpose_w=True)
-            l2 = ops.colsums(dN2, H2, f2[0], f2[1]); g2s, _ = model._bn_global(l2)
-            setg(c + "5.weight", l2[:, 1]); setg(c + "5.bias", l2[:, 0])
+            G[c + "5.weight"], G[c + "5.bias"] = newg(c + "5.weight"), newg(c + "5.bias")
+            l2 = ops.colsums(dN2, H2, f2[0], f2[1], out0=G[c + "5.bias"], out1=G[c + "5.weight"])
+            g2s, _ = model._bn_global(l2)
             dH2 = ops.bn2d_bwd(dN2, H2, g2s, B, P[c + "5.weight"], f2[0], f2[1], True, count_dev=cdev(5))
             G[c + "3.weight"] = ops.dense_wgrad(dH2, H1, newg(c + "3.weight"), ps=f1[2], pt=f1[3])
-            setg(c + "3.bias", ops.colsums(dH2)[:, 0])
+            G[c + "3.bias"] = newg(c + "3.bias"); ops.colsums(dH2, out0=G[c + "3.bias"])
             dN1 = ops.dense(dH2, P[c + "3.weight"], None, 128, 64, transpose_w=True)
-            l1 = ops.colsums(dN1, H1, f1[0], f1[1]); g1s, _ = model._bn_global(l1)
-            setg(c + "2.weight", l1[:, 1]); setg(c + "2.bias", l1[:, 0])
+            G[c + "2.weight"], G[c + "2.bias"] = newg(c + "2.weight"), newg(c + "2.bias")
+            l1 = ops.colsums(dN1, H1, f1[0], f1[1], out0=G[c + "2.bias"], out1=G[c + "2.weight"])
+            g1s, _ = model._bn_global(l1)
             dH1 = ops.bn2d_bwd(dN1, H1, g1s, B, P[c + "2.weight"], f1[0], f1[1], True, count_dev=cdev(4))
             G[c + "0.weight"] = ops.dense_wgrad(dH1, S["pooled"], newg(c + "0.weight"))
-            setg(c + "0.bias", ops.colsums(dH1)[:, 0])
+            G[c + "0.bias"] = newg(c + "0.bias"); ops.colsums(dH1, out0=G[c + "0.bias"])
             return ops.dense(dH1, P[c + "0.weight"], None, 256, 128, transpose_w=True)
 
         # ======================= sex classifier: pooling + TDNN (its input gradient is an addend

@@ -316,7 +316,8 @@ extern "C" int sa_dense(const float* X, int lda, const float* ps, const float* p
 // where Xh = X (sumsq, Xh null) or a second matrix (e.g. normalised activations).
 __global__ void sa_colsums_kernel(const float* __restrict__ X, const float* __restrict__ H,
                                   const float* __restrict__ hm, const float* __restrict__ hr,
-                                  int M, int N, double* sums) {
+                                  int M, int N, double* sums, float* __restrict__ out0,
+                                  float* __restrict__ out1) {
   const int n = blockIdx.x * blockDim.x + threadIdx.x;
   if (n >= N) return;
   double s = 0.0, q = 0.0;
@@ -328,13 +329,16 @@ __global__ void sa_colsums_kernel(const float* __restrict__ X, const float* __re
     s += x; q += (double)x * h;
   }
   sums[2 * n] = s; sums[2 * n + 1] = q;
+  if (out0) out0[n] = (float)s;
+  if (out1) out1[n] = (float)q;
 }
 
 extern "C" int sa_colsums(const float* X, const float* H, const float* hmean, const float* hrstd,
-                          int M, int N, double* sums, void* stream) {
+                          int M, int N, double* sums, float* out0, float* out1, void* stream) {
   if (!X || !sums) return -22;
   hipLaunchKernelGGL(sa_colsums_kernel, dim3(sa_div_up(N, 64)), dim3(64), 0,
-                     reinterpret_cast<hipStream_t>(stream), X, H, hmean, hrstd, M, N, sums);
+                     reinterpret_cast<hipStream_t>(stream), X, H, hmean, hrstd, M, N, sums, out0,
+                     out1);
   hipError_t e = hipGetLastError();
   return e == hipSuccess ? 0 : -(int)e;
 }

@@ -515,11 +515,16 @@ def dense(X, W, bias, N, K, ps=None, pt=None, relu=False, transpose_w=False):
     return Y
 
 
-def colsums(X, H=None, hmean=None, hrstd=None):
+def colsums(X, H=None, hmean=None, hrstd=None, out0=None, out1=None):
+    """out0 / out1: fp32 [N] tensors (parameter-gradient views) that receive columns 0 / 1 of the
+    fp64 sums rounded to fp32 -- no separate copy launch"""
     lib = L.load()
     M, N = X.shape
     s = torch.empty(N, 2, dtype=torch.float64, device=X.device)
-    L.check(lib.sa_colsums(_f(X), _f(H), _f(hmean), _f(hrstd), M, N, _f(s), L.stream()), "sa_colsums")
+    for o in (out0, out1):
+        assert o is None or (o.dtype == torch.float32 and o.numel() == N and o.is_contiguous())
+    L.check(lib.sa_colsums(_f(X), _f(H), _f(hmean), _f(hrstd), M, N, _f(s), _f(out0), _f(out1), L.stream()),
+            "sa_colsums")
     return s
 
 
