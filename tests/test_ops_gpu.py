@@ -1117,3 +1117,37 @@ def test_reduce_finalize_equals_the_separate_launches(B, nslab, Cc):
         assert torch.equal(b0, b1)
     torch.cuda.synchronize()
     assert int(ops._tickets[torch.device(d)].abs().sum()) == 0        # every ticket went back to zero
+
+
+@pytest.mark.parametrize("shape", [(5, 128, 128), (3, 128, 128), (5, 64, 64), (5, 32, 64), (3, 64, 32)],
+                         ids=lambda s: "x".join(map(str, s)))
+def test_wgrad_reduce_row_widths_and_tails(shape):
+    """sa_wgrad_reduce alone: every row width of the reducer (4 / 2 / 1 outputs per lane, chosen from
+    ntaps*cin*cout), slab counts that end inside, at and just behind the unrolled eight-load group,
+    the PyTorch-layout scatter (Conv1d [co][ci][k] and ConvTranspose1d [ci][co][k] strides) and
+    accumulate -- against a float64 sum on the host"""
+    import ctypes as C
+    from speech_anonymization_amd import _lib as L
+    lib = L.load()
+    nt, cin, cout = shape
+    per = nt * cin * cout
+    g = torch.Generator().manual_seed(per)
+    for nslab in (1, 3, 31, 32, 33, 67, 260):
+        slabs = torch.randn(nslab, nt, cin, cout, generator=g)
+        want = slabs.double().sum(0)                                   # [t][ci][co]
+        for layout in ("conv", "convT"):
+            if layout == "conv":                                       # dst [co][ci][k]
+                dst0 = torch.randn(cout, cin, nt, generator=g)
+                sk, sn, st = nt, cin * nt, 1
+                ref = want.permute(2, 1, 0)
+            else:                                                      # dst [ci][co][k]
+                dst0 = torch.randn(cin, cout, nt, generator=g)
+                sk, sn, st = cout * nt, nt, 1
+                ref = want.permute(1, 2, 0)
+            for acc in (0, 1):
+                dst = dst0.clone().to(dev())
+                sl = slabs.to(dev()).contiguous()
+                rc = lib.sa_wgrad_reduce(L.ptr(sl), L.ptr(dst), nslab, nt, cin, cout, sk, sn, st, acc, L.stream())
+                assert rc == 0
+                exp = (ref + dst0.double() if acc else ref).float()
+                torch.testing.assert_close(dst.cpu(), exp, rtol=2e-6, atol=2e-6 * max(1.0, nslab ** 0.5))
