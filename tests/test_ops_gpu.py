@@ -1151,3 +1151,25 @@ def test_wgrad_reduce_row_widths_and_tails(shape):
                 assert rc == 0
                 exp = (ref + dst0.double() if acc else ref).float()
                 torch.testing.assert_close(dst.cpu(), exp, rtol=2e-6, atol=2e-6 * max(1.0, nslab ** 0.5))
+
+
+def test_colsums_writes_fp32_gradient_views():
+    """sa_colsums out0 / out1: the fp64 column sums rounded to fp32, written into (possibly offset)
+    views of a flat bucket -- what the FC-head bias / BatchNorm-affine gradients use instead of a
+    copy launch; bit-equal to converting the fp64 sums"""
+    from speech_anonymization_amd import ops
+    g = torch.Generator().manual_seed(11)
+    M, N = 32, 128
+    X, H = torch.randn(M, N, generator=g).to(dev()), torch.randn(M, N, generator=g).to(dev())
+    hm, hr = torch.randn(N, generator=g).to(dev()), (torch.rand(N, generator=g) + 0.5).to(dev())
+    flat = torch.full((3 * N + 5,), 7.0, device=dev())
+    o0, o1 = flat[5:5 + N], flat[5 + 2 * N:5 + 3 * N]
+    s = ops.colsums(X, H, hm, hr, out0=o0, out1=o1)
+    assert torch.equal(o0, s[:, 0].float()) and torch.equal(o1, s[:, 1].float())
+    assert bool((flat[:5] == 7).all()) and bool((flat[5 + N:5 + 2 * N] == 7).all())
+    ref0 = X.double().sum(0)
+    ref1 = (X.double() * ((H.double() - hm.double()) * hr.double())).sum(0)
+    torch.testing.assert_close(s[:, 0], ref0, rtol=1e-6, atol=1e-6)
+    torch.testing.assert_close(s[:, 1], ref1, rtol=1e-5, atol=1e-5)
+    s2 = ops.colsums(X)                                   # no outputs: sums only (sum, sum of squares)
+    torch.testing.assert_close(s2[:, 1], (X.double() ** 2).sum(0), rtol=1e-6, atol=1e-6)
