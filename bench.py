@@ -225,6 +225,11 @@ def run_config(args, batch_size, rank, world, device, profile_key=None, graph=No
     for _ in range(SETUP_STEPS + args.warmup):
         brain.step += 1
         brain.fit_batch(batch)
+    # what Brain.fit does after its first steps: without it the interpreter's first full garbage
+    # collection (~100 ms of host time, ~60 steps into the process) lands wherever the step count
+    # puts it -- possibly inside the timed region, where it would cost ten steps' worth of idle GPU
+    from speech_anonymization_amd.brain import settle_python_heap
+    settle_python_heap()
     sync_all()
     if profile_key and not graph:
         ops.PROFILE.enable(profile_key)               # dominant kernel: timed live with HIP events
