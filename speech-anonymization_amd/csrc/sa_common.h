@@ -72,9 +72,13 @@ template <> struct Tr<bf16_t> {
 // in every prologue)
 __device__ static inline float sa_swish(float v) { return v * __builtin_amdgcn_rcpf(1.0f + __expf(-v)); }
 // d/dv [v * sigmoid(v)] = s * (1 + v * (1 - s))
+// (spelled out operation by operation: the weight-stationary data-gradient kernel, sa_conv_wsd.hip,
+// issues exactly these instructions from its filler slots and must produce the same bits)
 __device__ static inline float sa_swish_grad(float v) {
-  float s = __builtin_amdgcn_rcpf(1.0f + __expf(-v));
-  return s * (1.0f + v * (1.0f - s));
+  const float s = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(v * -1.4426950408889634f));
+  const float t = 1.0f - s;
+  const float u = fmaf(v, t, 1.0f);
+  return s * u;
 }
 
 // Row of the C/D accumulator of a 32x32 MFMA held in register `reg` of lane `lane`

@@ -599,6 +599,10 @@ bool sa_conv_ws_covers(int dtype, int cin, int cout, int sa, int u, const SaConv
 int sa_conv_ws_dispatch(int cin, int cout, const SaConvArgs* a, hipStream_t st);
 int sa_conv_ws_tile_rows(int cout);
 int sa_conv_ws_rows_per_tile(int cout);
+// (3): the fused data gradients 128 -> 128 that sa_conv_wsd.hip covers (normalisation-backward prologue
+// and / or fused backward epilogue) go to that kernel under the same conditions.
+bool sa_conv_wsd_covers(int dtype, int cin, int cout, int sa, int u, const SaConvArgs* a);
+int sa_conv_wsd_dispatch(int cin, int cout, const SaConvArgs* a, hipStream_t st);
 static int g_use_pp = 0, g_use_ws = 1;
 extern "C" int sa_conv_gemm_set_impl(int impl) {
   if (impl < 0 || impl > 2) return -22;
@@ -666,13 +670,16 @@ extern "C" int sa_abi_sizeof(int which) {
   }
 }
 
-// which kernel sa_conv_gemm routes this launch to: 0 one-tile, 1 ping-pong, 2 weight-stationary
+// which kernel sa_conv_gemm routes this launch to: 0 one-tile, 1 ping-pong, 2 weight-stationary, 3 weight-stationary fused data gradient
 static int conv_route(int dtype, int cin, int cout, int sa, int u, const SaConvArgs* a) {
   if (uses_pp(dtype)) return 1;
   if (g_use_ws && sa_conv_ws_covers(dtype, cin, cout, sa, u, a) &&
       tile_rows(cin, cout, u) == sa_conv_ws_tile_rows(cout) &&
       (long)a->B * sa_div_up(a->Lout, sa_conv_ws_rows_per_tile(cout)) >= 1536)
     return 2;
+  if (g_use_ws && sa_conv_wsd_covers(dtype, cin, cout, sa, u, a) && tile_rows(cin, cout, u) == 64 &&
+      (long)a->B * sa_div_up(a->Lout, 64) >= 1536)
+    return 3;
   return 0;
 }
 extern "C" int sa_conv_gemm_route(int dtype, int cin, int cout, int sa, int u, const SaConvArgs* a) {
@@ -689,6 +696,7 @@ extern "C" int sa_conv_gemm(int dtype, int cin, int cout, int sa, int u, const S
   const int route = conv_route(dtype, cin, cout, sa, u, a);
   if (route == 1) return sa_conv_pp_dispatch(dtype, cin, cout, sa, u, a, st);
   if (route == 2) return sa_conv_ws_dispatch(cin, cout, a, st);
+  if (route == 3) return sa_conv_wsd_dispatch(cin, cout, a, st);
   SA_CONV_CASE(32, 64, 2, 1)
   SA_CONV_CASE(64, 64, 1, 1)
   SA_CONV_CASE(64, 128, 2, 1)

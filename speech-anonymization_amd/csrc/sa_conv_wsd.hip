@@ -1,0 +1,880 @@
+// Fused DATA-GRADIENT convolutions 128 -> 128 (bf16x3 policy: fp32 storage, split-bf16 operands) in
+// the weight-stationary, persistent, LDS-DMA-pipelined form -- the backward of
+// models/ConvAutoEncoder.py:150-158 (encoder.11), :161 (decoder.0) and :33-43 (the three TDNN layers of
+// the sex classifier) reached from speechbrain_convae_train.py:241.
+//
+// One launch = normalisation-backward PROLOGUE of the layer above (d y = c1*dz + c2*y + c3 [* (y > 0)]
+// formed while the rows are staged; by-products bf16(d y) for the weight gradient and the column sums
+// for the bias gradient) + data-gradient convolution + activation / normalisation backward EPILOGUE of
+// the layer below (g' = (acc + g2) * swish'(z), statistics (sum g', sum g'*xhat)).  Same arguments,
+// slab geometry and output BITS (y, a_out) as sa_conv_gemm_kernel<bf16x3_t,128,128,1,1,64,PRO2>.
+//
+// Structure (what sa_conv_ws.hip does for the forward launches, re-cut so that the two extra input
+// tensors of a fused data gradient fit the register file):
+//   * one persistent 4-wave workgroup per CU, one wave per SIMD, the whole 512-register file; wave w
+//     owns output columns [32w, 32w+32) and keeps its weight fragments (taps x 8 k-steps x hi, lo) in
+//     registers for the launch (5 taps: 256 AGPRs + 64 VGPRs);
+//   * a 64-row tile is computed as two 32-row SECTIONS one after the other, each on ONE 32x32
+//     accumulator: acc[0] for rows 0..31, acc[1] for rows 32..63.  The epilogue of a section runs in
+//     the issue gaps of the NEXT section's MFMA loop straight from its accumulator -- no copy, and 32
+//     accumulator registers instead of the forward kernel's 128, which is what pays for the epilogue's
+//     state (stored-tensor values in flight, per-value pipeline registers);
+//   * input rows (d z and the stored forward tensor y of the layer above) arrive by LDS-DMA two tiles
+//     ahead; the stored tensor of the layer below (ep_x) and the second gradient (ep_g2) are loaded
+//     by the lanes that need them (a register of a 32x32 accumulator = two 128-byte row segments per
+//     load / store) one section ahead of their use;
+//   * every section is NT*24 single-MFMA statements with a filler slot behind each:
+//       slots E0..      epilogue of the previous section, software-pipelined over its 16 values (one
+//                       dependence level of up to four values per slot), behind COUNTED s_waitcnt
+//                       vmcnt(N): N = the vector-memory operations this wave is guaranteed to have
+//                       issued after the value's load (WsdSched::nwait) -- later DMA, stores and loads
+//                       stay in flight;
+//       slots T0..      transform of the next tile's pieces (prologue arithmetic, hi / lo split, operand
+//                       planes, bf16 d y, refill DMA of the tile after next) and the loads for the
+//                       next section's epilogue;
+//     LDS instructions sit in slot 0 of a 3-MFMA step only (hipcc waits lgkmcnt(0) in front of a
+//     step's first MFMA, whose A fragments were requested one step ahead);
+//   * tiles at the ends of an utterance, partial output tiles, the first tile of a workgroup and a
+//     tile range crossing an utterance take a plain path (no overlap, vmcnt(0) everywhere).
+// tools/wsd_audit.py checks the ISA (no spills, accumulators pinned, no compiler write to them inside
+// a tile body, loaded registers untouched between load and wait).
+#include "sa_conv_ws_common.h"
+
+namespace {
+
+// ---- the slot schedule of one instantiation (compile-time; shared by the filler and the wait counts) ----
+// PRO: 0 plain rows (decoder.0's data gradient: its input needs no apply), 2 normalisation-backward prologue
+// EP : 1 (acc) * swish'(z), xhat from x            [InstanceNorm + x*sigmoid(x) block]
+//      2 acc, xhat from x                          [ReLU + BatchNorm blocks; per-channel mean / rstd]
+//      3 acc, xhat from swish(z)                   [the classifier's input BatchNorm on the activation]
+//      4 (acc + k1*g2 + k2*swish(z) + k3) * swish'(z)   [mode 1 with the pending BatchNorm apply as addend]
+template <int NT_, int HALO_, int PRO_, int EP_>
+struct WsdSched {
+  typedef WsGeo<128, NT_, HALO_> G;
+  static constexpr int NS = NT_ * G::KSTEPS;              // k-steps per section
+  static constexpr int SECT = NS * 3;                     // MFMAs = slots per section (120 / 72)
+  static constexpr int DPW = G::DPW;
+  static constexpr int NP0 = (DPW + 1) / 2, NP1 = DPW - NP0;   // pieces transformed in section 0 / 1
+  static constexpr int LPV = EP_ == 4 ? 2 : 1;            // loads per epilogue value
+  static constexpr int EII = EP_ == 1 || EP_ == 4 ? 3 : EP_ == 3 ? 2 : 1; // slots between two values
+  static constexpr int ELV = EP_ == 1 ? 11 : EP_ == 4 ? 13 : EP_ == 3 ? 9 : 3;  // dependence levels of a value
+  static constexpr int LVG = EP_ == 1 ? 9 : EP_ == 4 ? 11 : EP_ == 3 ? 5 : 1;   // level that leaves the final value in the load's register
+  static constexpr int E0 = 3;                            // first epilogue slot (MFMA -> VALU distance)
+  static constexpr int EEND = E0 + 15 * EII + ELV;        // first slot behind the epilogue arithmetic: the statistics
+  // Vector-memory loads retire in order among themselves (LDS-DMA included) and stores among themselves,
+  // but NOT loads relative to stores: a counted vmcnt(N) is exact only while every operation younger
+  // than the awaited load is a load.  So a section first consumes its values (waits, arithmetic; the
+  // final value of value v replaces x in the load's own register), then stores all 16 in a burst, two
+  // per slot from slot SB, and only then issues the loads for the next section, one value per slot
+  // from slot LB -- no store of a section is younger than any of its loads.
+  static constexpr int SB = E0 + 15 * EII + LVG + 1, LB = SB + 8;
+  static constexpr int SUBS = PRO_ == 0 ? 6 : NT_ == 5 ? 12 : 9;          // slots per transform piece
+  static constexpr int T0 = SECT - NP0 * SUBS;            // first transform slot (both sections)
+  // piece-relative slots: raw read of the NEXT piece, operand-plane writes, d y cache, refill DMA
+  // (the raw read sits as late as the LDS latency allows: its eight registers then reuse the ones the
+  // split has just released)
+  static constexpr int KR = SUBS == 12 ? 9 : SUBS == 9 ? 6 : 3, KWH = SUBS == 6 ? 3 : 6, KWL = SUBS == 12 ? 9 : KWH;
+  static constexpr int KC = SUBS == 6 ? 5 : 7, KD0 = SUBS == 6 ? 4 : SUBS == 9 ? 7 : 8, KD1 = SUBS == 9 ? 8 : 10;
+  static_assert(T0 % 3 == 0 && SUBS % 3 == 0, "LDS instructions in slot 0 of a step");
+  static_assert(EEND < SECT && LB + 16 <= SECT, "epilogue, store burst and loads fit a section");
+  // refill DMAs guaranteed in slots > f of section s (the tile's last piece exists on some waves only)
+  static constexpr int dma_after(int s, int f) {
+    int n = 0;
+    const int np = s == 0 ? NP0 : NP1;
+    for (int p = 0; p < np; ++p) {
+      const int j = s == 0 ? p : NP0 + p;
+      if (j == DPW - 1) continue;
+      n += (T0 + p * SUBS + KD0 > f) ? 1 : 0;
+      if (PRO_ == 2) n += (T0 + p * SUBS + KD1 > f) ? 1 : 0;
+    }
+    return n;
+  }
+  // counted wait of value v, consumed in the section behind section s: its loads were issued in slot
+  // LB + v of section s; guaranteed younger operations = the later loads and the later refill DMAs of
+  // section s -- loads all of them.  (The d y cache and statistics stores in between are conditional
+  // and not counted: a pending one only makes the wait stricter.)
+  static constexpr int nwait(int s, int v) { return (15 - v) * LPV + dma_after(s, LB + v); }
+};
+
+// LDS-DMA piece with the destination formed in the statement: M0 = base + immediate (s_add_u32 writes SCC)
+__device__ static inline void wsd_dma16i(const void* gbase, unsigned voff, unsigned lds_base, int imm) {
+  unsigned keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_add_u32 m0, %3, %4\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep) : "v"(voff), "s"(gbase), "s"(lds_base), "n"(imm) : "memory", "scc");
+}
+
+// The stored-tensor values of the pending section (and the second gradient, EP 4) are loaded by asm a
+// whole section ahead of their use, across the tile loop's back edge.  hipcc does not know that such a
+// register is in flight: as a C++ variable it gets copied into the loop-carried register at the loop
+// header while the load has not landed (found as intermittently stale values; "+v" ties and register
+// variables do not prevent the copy).  So these values live in RESERVED registers: amdgpu_num_vgpr
+// keeps hipcc's allocation below them, and every access -- load, the levels that read or replace the
+// value, store, statistics -- is an asm statement that names the register literally: v240 + i for
+// the stored tensor, a240 + i for the second gradient (amdgpu_num_vgpr(240) caps both files; a global
+// load may target an accumulator register, v_accvgpr_read fetches the value once it has landed).  In
+// the kernels without a second gradient a240..a255 hold two more (tap, k-step) pairs of weights,
+// placed and named by hand.  tools/wsd_audit.py checks that no compiler-generated instruction touches
+// the reserved registers.
+#define WSD_XR0 240
+template <int NT, int HALO, int PRO, int EP>
+__device__ __forceinline__ void wsd_body(const SaConvArgs& a, int tiles_per_wg, int total_tiles) {
+  typedef WsGeo<128, NT, HALO> G;
+  typedef WsdSched<NT, HALO, PRO, EP> Sch;
+  constexpr int WS_C = 128, WS_TM = 64, WS_KSTEPS = G::KSTEPS, WS_PITCH = G::PITCH, RPP = G::RPP, LPR = G::LPR;
+  constexpr int WS_NTAPS = NT, WS_ROWS = G::ROWS, WS_PLANE = G::PLANE, WS_NDMA = G::NDMA, WS_DPW = G::DPW,
+                WS_RAW_BYTES = G::RAW_BYTES, WS_BUF_BYTES = G::BUF_BYTES,
+                // (tap, k-step) pairs whose fragments live in AGPRs: amdgpu_num_vgpr(240) caps the accumulator
+                // file at 240 registers too (30 pairs); the last 16 (a240..a255) hold the second gradient (EP 4)
+                WS_NAGPR_FRAGS = NT * G::KSTEPS < 30 ? NT * G::KSTEPS : 30,
+                // ... or, without one, pairs 30 and 31 by hand: hi a[240:243] / lo a[244:247], hi a[248:251] / lo a[252:255]
+                WS_NHAND = (EP != 4 && NT * G::KSTEPS > 30) ? 2 : 0;
+  constexpr bool PRO2 = PRO == 2;
+  constexpr bool ACT = EP == 1 || EP == 3 || EP == 4;       // the epilogue evaluates z = x*s1 + t1 and sigmoid(z)
+  constexpr float NL2E = -1.4426950408889634f;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  // LDS: [operand buffer 0][operand buffer 1][raw tile x][raw tile nb_x (PRO2)][column-sum scratch (PRO2)]
+  bf16_t* const planes = reinterpret_cast<bf16_t*>(smem);
+  unsigned char* const raw = smem + 2 * WS_BUF_BYTES;
+  const unsigned raw_lds = (unsigned)(uintptr_t)(lds_byte*)raw;
+  unsigned raw_lds_w = raw_lds + (unsigned)__builtin_amdgcn_readfirstlane(threadIdx.x >> 6) * 1024;   // this wave's piece 0
+  asm volatile("" : "+s"(raw_lds_w));
+  const int tid = threadIdx.x, lane_ = tid & 63;
+  const int wave_ = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int first = blockIdx.x * tiles_per_wg;
+  int last = first + tiles_per_wg;
+  if (last > total_tiles) last = total_tiles;
+  if (first >= last) return;
+
+  // ---- the weights: this wave's 32 output columns, all taps / channels, hi and lo images ----
+  bf16x8 Bh[WS_NTAPS][WS_KSTEPS], Bl[WS_NTAPS][WS_KSTEPS];
+  {
+    const bf16x8* wp = reinterpret_cast<const bf16x8*>(a.wp);
+#pragma unroll
+    for (int t = 0; t < WS_NTAPS; ++t) {
+      const bf16x8* wt = wp + ((size_t)a.taps.widx[0][t] * WS_KSTEPS * 4 + wave_) * 64 + lane_;
+#pragma unroll
+      for (int k = 0; k < WS_KSTEPS; ++k) {
+        Bh[t][k] = wt[(size_t)k * 4 * 64];
+        Bl[t][k] = wt[(size_t)a.wlo_off + (size_t)k * 4 * 64];
+      }
+      // one tap at a time, moved to its home before the next tap is fetched; the empty asm also makes
+      // hipcc wait for the loads HERE and not in front of their first use inside the tile loop
+#pragma unroll
+      for (int k = 0; k < WS_KSTEPS; ++k) {
+        const int pr = t * WS_KSTEPS + k;
+        if (pr < WS_NAGPR_FRAGS) {
+          asm volatile("" : "+a"(Bh[t][k]), "+a"(Bl[t][k]));
+        } else if (pr < WS_NAGPR_FRAGS + WS_NHAND) {
+          typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+          const u32x4 uh = __builtin_bit_cast(u32x4, Bh[t][k]), ul = __builtin_bit_cast(u32x4, Bl[t][k]);
+          if (pr == 30)
+            asm volatile("v_accvgpr_write_b32 a240, %0\n\tv_accvgpr_write_b32 a241, %1\n\tv_accvgpr_write_b32 a242, %2\n\tv_accvgpr_write_b32 a243, %3\n\t"
+                         "v_accvgpr_write_b32 a244, %4\n\tv_accvgpr_write_b32 a245, %5\n\tv_accvgpr_write_b32 a246, %6\n\tv_accvgpr_write_b32 a247, %7"
+                         :: "v"(uh[0]), "v"(uh[1]), "v"(uh[2]), "v"(uh[3]), "v"(ul[0]), "v"(ul[1]), "v"(ul[2]), "v"(ul[3]));
+          else
+            asm volatile("v_accvgpr_write_b32 a248, %0\n\tv_accvgpr_write_b32 a249, %1\n\tv_accvgpr_write_b32 a250, %2\n\tv_accvgpr_write_b32 a251, %3\n\t"
+                         "v_accvgpr_write_b32 a252, %4\n\tv_accvgpr_write_b32 a253, %5\n\tv_accvgpr_write_b32 a254, %6\n\tv_accvgpr_write_b32 a255, %7"
+                         :: "v"(uh[0]), "v"(uh[1]), "v"(uh[2]), "v"(uh[3]), "v"(ul[0]), "v"(ul[1]), "v"(ul[2]), "v"(ul[3]));
+        } else {
+          asm volatile("" : "+v"(Bh[t][k]), "+v"(Bl[t][k]));
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+  float bv = a.bias ? a.bias[wave_ * 32 + (lane_ & 31)] : 0.0f;
+  unsigned mask_bits = a.nb_relu_mask ? 0u : 0xff800000u;       // y > -inf: no mask, no branch in the slot (uniform: a scalar register)
+  const bool has_stats = a.stats != nullptr, has_ao = a.a_out != nullptr;
+
+  // ---- lane constants of the filler slots (opaque: hipcc keeps THESE and derives per-slot addresses
+  // from them by immediates instead of hoisting one address chain per slot) ----
+  const int half_ = lane_ >> 5, l31_ = lane_ & 31;             // accumulator layout: rows +4, column
+  const int rowp_ = lane_ / LPR, cq_ = lane_ % LPR;            // transform layout: row of the piece, channel quad
+  unsigned row0 = RPP * wave_ + rowp_;
+  unsigned raw_off = wave_ * 1024 + lane_ * 16;            // byte offset in the raw tile and in the row block of a DMA tile: + j*4096
+  unsigned pl_off = (row0 * WS_PITCH + cq_ * 4) * 2;       // byte offset in an operand plane: + j*4*RPP*PITCH*2
+  unsigned ao_off = (row0 * WS_C + cq_ * 4) * 2;           // byte offset in the a_out row block: + j*4*RPP*C*2
+  unsigned y_off = ((4 * half_) * WS_C + wave_ * 32 + l31_) * 4;   // byte offset in a [64][128] fp32 row block: + ro*512
+  asm volatile("" : "+s"(mask_bits));
+  const float mask_thr = __uint_as_float(mask_bits);
+  asm volatile("" : "+v"(bv), "+v"(row0), "+v"(raw_off), "+v"(pl_off), "+v"(ao_off), "+v"(y_off));
+
+#define WS_IDS int lane = lane_, wave = wave_; asm volatile("" : "+v"(lane), "+s"(wave)); (void)wave; (void)lane
+
+  struct Tile { int b, tile; };
+  auto tile_of = [&](int t) { Tile r; r.b = t / a.ntiles; r.tile = t - r.b * a.ntiles; return r; };
+  auto next_tile = [&](Tile T) { Tile r; const bool wrap = T.tile + 1 == a.ntiles; r.b = wrap ? T.b + 1 : T.b; r.tile = wrap ? 0 : T.tile + 1; return r; };
+  // rows outside the utterance among the staged ones, or the trailing rows it owns beyond its 64
+  auto is_edge = [&](Tile T) {
+    const int g0 = T.tile * WS_TM + a.rowmin;
+    return g0 < 0 || g0 + WS_ROWS > a.Lin || T.tile == a.ntiles - 1;
+  };
+  auto is_partial = [&](Tile T) { return T.tile * WS_TM + WS_TM > a.Lout; };
+
+  // ---- constants: prologue coefficients per (utterance | -, channel quad); epilogue per column ----
+  float k1[4], k2[4], k3[4];
+  int cur_b = -1;
+  auto load_consts = [&](int b) {
+    if constexpr (PRO2) {
+      WS_IDS;
+      const int ch = (lane % LPR) * 4;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const size_t q = (size_t)b * a.nb_bstride + ch + j;
+        k1[j] = a.nb_c1[q]; k2[j] = a.nb_c2[q]; k3[j] = a.nb_c3[q];
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) asm volatile("" : "+v"(k1[j]), "+v"(k2[j]), "+v"(k3[j]));   // waited for here
+    }
+    cur_b = b;
+  };
+  float es1 = 1.0f, et1 = 0.0f, emu = 0.0f, ers = 1.0f, gk1 = 1.0f, gk2 = 0.0f, gk3 = 0.0f;
+  int cur_eb = -1;
+  auto load_ep_consts = [&](int b) {
+    WS_IDS;
+    const int col = wave * 32 + (lane & 31);
+    if constexpr (ACT) { es1 = a.ep_s1[(size_t)b * WS_C + col]; et1 = a.ep_t1[(size_t)b * WS_C + col]; }
+    emu = a.ep_mean[(size_t)b * a.ep_bstride + col];
+    ers = a.ep_rstd[(size_t)b * a.ep_bstride + col];
+    if constexpr (EP == 4) { gk1 = a.ep_g2k1[col]; gk2 = a.ep_g2k2[col]; gk3 = a.ep_g2k3[col]; }
+    asm volatile("" : "+v"(es1), "+v"(et1), "+v"(emu), "+v"(ers), "+v"(gk1), "+v"(gk2), "+v"(gk3));
+    cur_eb = b;
+  };
+
+  // ---- uniform per-tile bases (set once per iteration, opaque) ----
+  const char* xbase_d = nullptr; const char* x2base_d = nullptr;    // rows of the DMA tile (x, nb_x)
+  char* aobase_t = nullptr;                                          // a_out rows of the transform tile
+  auto row_block = [&](const void* p, int b, int L, int row, int row_bytes) {
+    const char* r = reinterpret_cast<const char*>(p) + (long)(b * L + row) * row_bytes;   // B*L rows < 2^31 (checked at launch)
+    asm volatile("" : "+s"(r));
+    return r;
+  };
+  // a [64][128] fp32 row block addressed by 13-bit immediates: value (h, i) of a tile lives in row
+  // 32h + 8(i >> 2) + (i & 3) (+ 4 for the upper lane half): pointer = row 16q + 8 of the block with
+  // q = 2h + (i >> 3), immediate ((i >> 2) & 1 ? 0 : -4096) + (i & 3) * 512.  The slots walk the values in
+  // order, so each stream (y stores, ep_x loads, ep_g2 loads) keeps ONE running pointer, advanced by 16
+  // rows after every eighth value.
+  auto block8 = [&](const void* p, int b, int row) {       // row 8 of the tile's row block
+    const char* r = reinterpret_cast<const char*>(p) + ((long)(b * a.Lout + row) * WS_C + 8 * WS_C) * 4;
+    asm volatile("" : "+s"(r));
+    return r;
+  };
+  const char* yb_p = nullptr; const char* yb_c = nullptr; const char* xb_c = nullptr; const char* gb_c = nullptr;
+  const char* ycur = nullptr; const char* xcur = nullptr; const char* gcur = nullptr;
+#define WSD_IMM(i) ((((i) >> 2) & 1 ? 0 : -4096) + ((i) & 3) * 512)
+#define WSD_Q(h, i) (2 * (h) + ((i) >> 3))
+#define WSD_STEP16(p) do { p += 16 * WS_C * 4; asm volatile("" : "+s"(p)); } while (0)
+
+  // ---- LDS-DMA of piece j of this wave (rows RPP*i .., i = wave + 4j) of tile T ----
+  auto dma_piece = [&](Tile T, bool edge, int j, int part = 2) {
+    const int i = wave_ + 4 * j;
+    if (j == WS_DPW - 1 && i >= WS_NDMA) return;
+    if (!edge) {
+      // (LDS destination = this wave's first piece + an immediate, formed in the statement: no scalar
+      // register per piece)
+      if (part != 1) wsd_dma16i(xbase_d + j * 4096, raw_off, raw_lds_w, j * 4096);
+      if constexpr (PRO2) {
+        if (part != 0) wsd_dma16i(x2base_d + j * 4096, raw_off, raw_lds_w, WS_RAW_BYTES + j * 4096);
+      }
+    } else {
+      WS_IDS;
+      const int g0 = T.tile * WS_TM + a.rowmin;
+      int g = g0 + RPP * i + lane / LPR;
+      g = g < 0 ? 0 : (g >= a.Lin ? a.Lin - 1 : g);        // rows outside the utterance: any valid address (zeroed in the transform)
+      const size_t off = ((size_t)T.b * a.Lin + g) * (WS_C * 4) + (lane % LPR) * 16;
+      ws_dma16(reinterpret_cast<const char*>(a.x) + off, raw_lds + i * 1024);
+      if constexpr (PRO2) ws_dma16(reinterpret_cast<const char*>(a.nb_x) + off, raw_lds + WS_RAW_BYTES + i * 1024);
+    }
+  };
+
+  // ---- transform of a piece, in sub-steps (each small enough for one filler slot) ----
+  f32x4 vx[1], vy[1];
+  float f[4], csum[4], z[4], w[4];
+  uint2 phi, plo;
+  unsigned pl_cur = 0;                                     // LDS byte offset of this lane's first row in the transform tile's buffer
+  auto has_piece = [&](int j) { return !(j == WS_DPW - 1 && wave_ + 4 * j >= WS_NDMA); };
+  auto piece_read = [&](int j) {
+    if (!has_piece(j)) return;
+    vx[0] = *reinterpret_cast<const f32x4*>(raw + (raw_off + j * 4096));
+    if constexpr (PRO2) vy[0] = *reinterpret_cast<const f32x4*>(raw + (raw_off + WS_RAW_BYTES + j * 4096));
+  };
+  auto own_range = [&](Tile T, int& lo, int& hi) {
+    lo = T.tile * WS_TM;
+    hi = T.tile == a.ntiles - 1 ? a.Lin : lo + WS_TM;
+    if (hi > a.Lin) hi = a.Lin;
+  };
+  auto owns = [&](Tile T, bool edge, int j) -> bool {
+    if (!edge) {                                           // own rows = staged rows [-rowmin, -rowmin + TM)
+      if (j > 0 && j < WS_DPW - 2) return true;            // the middle pieces are owned in every geometry
+      const int r = (int)row0 + 4 * RPP * j;
+      return r >= -a.rowmin && r < -a.rowmin + WS_TM;
+    }
+    int lo, hi;
+    own_range(T, lo, hi);
+    const int g = T.tile * WS_TM + a.rowmin + (int)row0 + 4 * RPP * j;
+    return g >= lo && g < hi;
+  };
+  // hi = bf16(v), lo = bf16(v - hi) of a channel pair (same roundings as sa_split4; opaque inputs: the
+  // split must see the ROUNDED value, not an fma that formed it)
+  auto split_pair = [&](float a0, float a1, unsigned& hi, unsigned& lo) {
+    asm volatile("" : "+v"(a0), "+v"(a1));
+    hi = ws_cvt_pk_bf16(a0, a1);
+    lo = ws_cvt_pk_bf16(a0 - __uint_as_float(hi << 16), a1 - __uint_as_float(hi & 0xffff0000u));
+  };
+  auto piece_elem = [&](Tile T, bool edge, int j, int q) {            // plain path: channel q of the lane's four
+    if (!has_piece(j)) return;
+    float v = vx[0][q];
+    if constexpr (PRO2) {
+      const float y = vy[0][q];
+      v = fmaf(k1[q], v, fmaf(k2[q], y, k3[q]));
+      v = y > mask_thr ? v : 0.0f;
+      if (owns(T, edge, j)) csum[q] += v;
+    }
+    if (edge) {                                            // rows outside the utterance are zero operands
+      const int g = T.tile * WS_TM + a.rowmin + (int)row0 + 4 * RPP * j;
+      if (!(g >= 0 && g < a.Lin)) v = 0.0f;
+    }
+    f[q] = v;
+    if (q == 1) split_pair(f[0], f[1], phi.x, plo.x);
+    if (q == 3) split_pair(f[2], f[3], phi.y, plo.y);
+  };
+  // the same transform for an interior tile, cut by dependence level (one level of all four channels per slot)
+  auto piece_level = [&](Tile T, int j, int lv) {
+    if (!has_piece(j)) return;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      if constexpr (!PRO2) {
+        if (lv == 0) f[q] = vx[0][q];
+      } else {
+        if (lv == 0) z[q] = fmaf(k2[q], vy[0][q], k3[q]);
+        if (lv == 1) f[q] = fmaf(k1[q], vx[0][q], z[q]);
+        if (lv == 2) f[q] = vy[0][q] > mask_thr ? f[q] : 0.0f;
+        if (lv == 3) { if (owns(T, false, j)) csum[q] += f[q]; }
+      }
+    }
+  };
+  auto piece_split = [&](int j, int lv) {
+    if (!has_piece(j)) return;
+    if (lv == 0) {
+      asm volatile("" : "+v"(f[0]), "+v"(f[1]), "+v"(f[2]), "+v"(f[3]));
+      phi.x = ws_cvt_pk_bf16(f[0], f[1]); phi.y = ws_cvt_pk_bf16(f[2], f[3]);
+    }
+    if (lv == 1) {
+      z[0] = __uint_as_float(phi.x << 16); z[1] = __uint_as_float(phi.x & 0xffff0000u);
+      z[2] = __uint_as_float(phi.y << 16); z[3] = __uint_as_float(phi.y & 0xffff0000u);
+    }
+    if (lv == 2) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) w[q] = f[q] - z[q];
+    }
+    if (lv == 3) { plo.x = ws_cvt_pk_bf16(w[0], w[1]); plo.y = ws_cvt_pk_bf16(w[2], w[3]); }
+  };
+  auto piece_write = [&](int j, int part = 2) {             // operand planes of the transform tile (0 hi, 1 lo, 2 both)
+    if (!has_piece(j)) return;
+    unsigned char* dst = smem + (pl_cur + j * (4 * RPP * WS_PITCH * 2));
+    if (part != 1) *reinterpret_cast<uint2*>(dst) = phi;
+    if (part != 0) *reinterpret_cast<uint2*>(dst + WS_PLANE * 2) = plo;
+  };
+  auto piece_cache = [&](Tile T, bool edge, int j) {          // bf16 d y for sa_wgrad: hi values of the owned rows
+    if (!has_piece(j)) return;
+    if (has_ao && owns(T, edge, j)) ws_store_b64(aobase_t + j * (4 * RPP * WS_C * 2), ao_off, phi);
+  };
+  // per-tile column sums of d y (bias gradient): fold the two row halves of the wave, one LDS slot per
+  // wave, summed in wave order by 128 threads after the tile barrier
+  auto colsum_put = [&](int it) {
+    if constexpr (PRO2) {
+      if (a.nb_colsum) {
+        float* colred = reinterpret_cast<float*>(raw + 2 * WS_RAW_BYTES) + (size_t)(it & 1) * 4 * WS_C;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const float v = csum[q] + __int_as_float(__builtin_amdgcn_ds_bpermute((lane_ ^ 32) * 4, __float_as_int(csum[q])));
+          if (lane_ < 32) colred[wave_ * WS_C + (lane_ & 31) * 4 + q] = v;
+        }
+      }
+#pragma unroll
+      for (int q = 0; q < 4; ++q) csum[q] = 0.0f;
+    }
+  };
+  auto colsum_out = [&](int t, int it) {                    // after the barrier that follows colsum_put(it)
+    if constexpr (PRO2) {
+      if (a.nb_colsum && tid < WS_C) {
+        const float* colred = reinterpret_cast<const float*>(raw + 2 * WS_RAW_BYTES) + (size_t)(it & 1) * 4 * WS_C;
+        a.nb_colsum[(size_t)t * WS_C + tid] = (colred[tid] + colred[WS_C + tid]) + (colred[2 * WS_C + tid] + colred[3 * WS_C + tid]);
+      }
+    }
+  };
+
+  // ---- epilogue: one accumulator register = one value (row ro + 4*half, this lane's column) ----
+  f32x16 acc[2];
+  asm volatile("" ::: "v255", "a255");                    // (the kernel descriptor must cover the reserved registers)
+  float ez[8], ew[8], es[8], et[8], eg[8], exn[8], ea[8];   // per-value pipeline registers (value v uses v & 7)
+  float ssum = 0.0f, ssq = 0.0f;
+  // one dependence level of value (h, i); xq / gq / yq: the row-block bases of its tile.  The very
+  // operations of sa_conv_gemm's ep_rows, in its order (sa_swish / sa_swish_grad spelled out).
+  auto epi_level = [&](auto h_c, auto i_c, auto lv_c) {
+    constexpr int h = decltype(h_c)::value, i = decltype(i_c)::value, lv = decltype(lv_c)::value, r = i & 7;
+    (void)&ssum; (void)&ssq; (void)&y_off;
+  // (asm: hipcc otherwise sinks all the accumulations of a section, and the xhat arithmetic that feeds
+  // them, into the statistics slot behind its branch)
+#define WSD_ACC_SUM() asm volatile("v_add_f32 %0, %0, v%c1" : "+v"(ssum) : "n"(WSD_XR0 + i))
+#define WSD_ACC_SQ() asm volatile("v_fmac_f32 %0, v%c2, %1" : "+v"(ssq) : "v"(exn[r]), "n"(WSD_XR0 + i))
+  // x = the reserved register of value i: z = x*s1 + t1 | x - mean | x <- a*b | x <- a + b | ea += gk1*g2
+#define WSD_X_FMA(dst, m, c) asm volatile("v_fma_f32 %0, v%c3, %1, %2" : "=v"(dst) : "v"(m), "v"(c), "n"(WSD_XR0 + i))
+#define WSD_X_SUB(dst, c) asm volatile("v_sub_f32 %0, v%c2, %1" : "=v"(dst) : "v"(c), "n"(WSD_XR0 + i))
+#define WSD_X_SETMUL(a_, b_) asm volatile("v_mul_f32 v%c2, %0, %1" :: "v"(a_), "v"(b_), "n"(WSD_XR0 + i))
+#define WSD_X_SETADD(a_, b_) asm volatile("v_add_f32 v%c2, %0, %1" :: "v"(a_), "v"(b_), "n"(WSD_XR0 + i))
+#define WSD_G2_READ(dst) asm volatile("v_accvgpr_read_b32 %0, a%c1" : "=v"(dst) : "n"(WSD_XR0 + i))
+    // the last level that needs x writes the final value over it (in its reserved register): the store burst and the
+    // statistics read it there
+    if constexpr (EP == 1) {
+      if constexpr (lv == 0) WSD_X_FMA(ez[r], es1, et1);
+      if constexpr (lv == 1) ew[r] = ez[r] * NL2E;
+      if constexpr (lv == 2) ew[r] = __builtin_amdgcn_exp2f(ew[r]);
+      if constexpr (lv == 3) ew[r] = 1.0f + ew[r];
+      if constexpr (lv == 4) es[r] = __builtin_amdgcn_rcpf(ew[r]);
+      if constexpr (lv == 5) { et[r] = 1.0f - es[r]; eg[r] = acc[h][i] + bv; }
+      if constexpr (lv == 6) et[r] = fmaf(ez[r], et[r], 1.0f);
+      if constexpr (lv == 7) es[r] = es[r] * et[r];
+      if constexpr (lv == 8) WSD_X_SUB(exn[r], emu);
+      if constexpr (lv == 9) { WSD_X_SETMUL(eg[r], es[r]); exn[r] = exn[r] * ers; }
+      if constexpr (lv == 10) { WSD_ACC_SUM(); WSD_ACC_SQ(); }
+    } else if constexpr (EP == 4) {
+      if constexpr (lv == 0) WSD_X_FMA(ez[r], es1, et1);
+      if constexpr (lv == 1) ew[r] = ez[r] * NL2E;
+      if constexpr (lv == 2) ew[r] = __builtin_amdgcn_exp2f(ew[r]);
+      if constexpr (lv == 3) ew[r] = 1.0f + ew[r];
+      if constexpr (lv == 4) es[r] = __builtin_amdgcn_rcpf(ew[r]);
+      if constexpr (lv == 5) { et[r] = 1.0f - es[r]; ea[r] = ez[r] * es[r]; }
+      if constexpr (lv == 6) { et[r] = fmaf(ez[r], et[r], 1.0f); ea[r] = fmaf(gk2, ea[r], gk3); WSD_G2_READ(ew[r]); }
+      if constexpr (lv == 7) { es[r] = es[r] * et[r]; ea[r] = fmaf(gk1, ew[r], ea[r]); }
+      if constexpr (lv == 8) eg[r] = acc[h][i] + bv;
+      if constexpr (lv == 9) eg[r] = eg[r] + ea[r];
+      if constexpr (lv == 10) WSD_X_SUB(exn[r], emu);
+      if constexpr (lv == 11) { WSD_X_SETMUL(eg[r], es[r]); exn[r] = exn[r] * ers; }
+      if constexpr (lv == 12) { WSD_ACC_SUM(); WSD_ACC_SQ(); }
+    } else if constexpr (EP == 3) {
+      if constexpr (lv == 0) WSD_X_FMA(ez[r], es1, et1);
+      if constexpr (lv == 1) ew[r] = ez[r] * NL2E;
+      if constexpr (lv == 2) ew[r] = __builtin_amdgcn_exp2f(ew[r]);
+      if constexpr (lv == 3) ew[r] = 1.0f + ew[r];
+      if constexpr (lv == 4) es[r] = __builtin_amdgcn_rcpf(ew[r]);
+      if constexpr (lv == 5) { ea[r] = ez[r] * es[r]; WSD_X_SETADD(acc[h][i], bv); }
+      if constexpr (lv == 6) exn[r] = ea[r] - emu;
+      if constexpr (lv == 7) { exn[r] = exn[r] * ers; WSD_ACC_SUM(); }
+      if constexpr (lv == 8) WSD_ACC_SQ();
+    } else {
+      if constexpr (lv == 0) WSD_X_SUB(exn[r], emu);
+      if constexpr (lv == 1) { WSD_X_SETADD(acc[h][i], bv); exn[r] = exn[r] * ers; }
+      if constexpr (lv == 2) { WSD_ACC_SUM(); WSD_ACC_SQ(); }
+    }
+#undef WSD_X_FMA
+#undef WSD_X_SUB
+#undef WSD_X_SETMUL
+#undef WSD_X_SETADD
+#undef WSD_G2_READ
+#undef WSD_ACC_SUM
+#undef WSD_ACC_SQ
+  };
+  // store of value i (its final value sits in its reserved register); yp: the stream pointer of its row group
+  auto epi_store = [&](auto i_c, const char* yp) {
+    constexpr int i = decltype(i_c)::value;
+    (void)&y_off;
+    asm volatile("global_store_dword %0, v%c3, %1 offset:%2" :: "v"(y_off), "s"(yp), "n"(WSD_IMM(i)), "n"(WSD_XR0 + i) : "memory");
+  };
+  // loads of value i of a section (xp / gp: the stream pointers of its row group) into the reserved registers
+  auto epi_load = [&](auto i_c, const char* xp, const char* gp) {
+    constexpr int i = decltype(i_c)::value;
+    (void)&ssum; (void)&ssq; (void)&y_off;
+    asm volatile("global_load_dword v%c3, %0, %1 offset:%2" :: "v"(y_off), "s"(xp), "n"(WSD_IMM(i)), "n"(WSD_XR0 + i) : "memory");
+    if constexpr (EP == 4)
+      asm volatile("global_load_dword a%c3, %0, %1 offset:%2" :: "v"(y_off), "s"(gp), "n"(WSD_IMM(i)), "n"(WSD_XR0 + i) : "memory");
+  };
+  // whole section h of tile T outside the slots (plain loads, bounds-checked; everything older has landed)
+  auto epi_plain = [&](auto h_c, Tile T, const char* yb, const char* xb, const char* gb) {     // (row 8 of the row blocks)
+    constexpr int h = decltype(h_c)::value;
+    if (cur_eb != T.b) load_ep_consts(T.b);
+    auto in_bounds = [&](int i) {
+      WS_IDS;
+      return T.tile * WS_TM + 32 * h + (i & 3) + 8 * (i >> 2) + 4 * (lane >> 5) < a.Lout;
+    };
+    ws_static_for<0, 16>([&](auto i_c) {                    // all loads first, one wait
+      constexpr int i = decltype(i_c)::value;
+      if (in_bounds(i)) epi_load(i_c, xb + WSD_Q(h, i) * (16 * WS_C * 4), EP == 4 ? gb + WSD_Q(h, i) * (16 * WS_C * 4) : nullptr);
+    });
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    ws_static_for<0, 16>([&](auto i_c) {
+      constexpr int i = decltype(i_c)::value;
+      (void)&ssum; (void)&ssq; (void)&y_off;
+      if (in_bounds(i)) {
+        ws_static_for<0, Sch::ELV>([&](auto lv_c) { epi_level(h_c, i_c, lv_c); });
+        epi_store(i_c, yb + WSD_Q(h, i) * (16 * WS_C * 4));
+      }
+    });
+  };
+  // statistics of a tile: fold the two lane halves (a lane owns one column, the other half holds the
+  // rows +4) and store; both halves then hold the same sums and write the same slab entry
+  char* stbase_p = nullptr;
+  auto epi_stats = [&]() {
+    if (has_stats) {
+      const auto rs = __builtin_amdgcn_permlane32_swap(__float_as_uint(ssum), __float_as_uint(ssum), false, false);
+      const auto rq = __builtin_amdgcn_permlane32_swap(__float_as_uint(ssq), __float_as_uint(ssq), false, false);
+      const float st_s = __uint_as_float(rs[0]) + __uint_as_float(rs[1]);
+      const float st_q = __uint_as_float(rq[0]) + __uint_as_float(rq[1]);
+      WS_IDS;
+      ws_store_b64(stbase_p, (unsigned)((wave * 32 + (lane & 31)) * 8), make_uint2(__float_as_uint(st_s), __float_as_uint(st_q)));
+    }
+    ssum = 0.0f; ssq = 0.0f;
+  };
+  auto drain_vmem = [&]() {                                 // every asm load has landed in its register
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  };
+
+  int toff[WS_NTAPS];
+#pragma unroll
+  for (int t = 0; t < WS_NTAPS; ++t) toff[t] = (a.taps.off[0][t] - a.rowmin) * WS_PITCH;
+
+  // ================= prologue: first tile staged without overlap =================
+  Tile Tc = tile_of(first), Tn = tile_of(first + 1 < last ? first + 1 : last - 1), Tp = Tc;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) csum[q] = 0.0f;
+  {
+    const bool ec = is_edge(Tc), en = is_edge(Tn);
+    xbase_d = row_block(a.x, Tc.b, a.Lin, Tc.tile * WS_TM + a.rowmin, WS_C * 4);
+    if constexpr (PRO2) x2base_d = row_block(a.nb_x, Tc.b, a.Lin, Tc.tile * WS_TM + a.rowmin, WS_C * 4);
+    aobase_t = const_cast<char*>(row_block(a.a_out, Tc.b, a.Lin, Tc.tile * WS_TM + a.rowmin, WS_C * 2));
+    pl_cur = pl_off;
+#pragma unroll
+    for (int j = 0; j < WS_DPW; ++j) dma_piece(Tc, ec, j);
+    xbase_d = row_block(a.x, Tn.b, a.Lin, Tn.tile * WS_TM + a.rowmin, WS_C * 4);
+    if constexpr (PRO2) x2base_d = row_block(a.nb_x, Tn.b, a.Lin, Tn.tile * WS_TM + a.rowmin, WS_C * 4);
+    load_consts(Tc.b);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+    for (int j = 0; j < WS_DPW; ++j) {
+      piece_read(j);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) piece_elem(Tc, ec, j, q);
+      piece_write(j);
+      piece_cache(Tc, ec, j);
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the raw piece is in registers before its refill
+      dma_piece(Tn, en, j);
+    }
+  }
+  colsum_put(0);
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  colsum_out(first, 0);
+
+  // ================= the tile walk =================
+  // iteration (t, it): section 0 = MFMAs of rows 0..31 of tile t -> acc[0], in its slots the epilogue of
+  // rows 32..63 of tile t-1 (acc[1]), the loads for the epilogue of rows 0..31 of tile t, the transform
+  // of pieces 0..NP0-1 of tile t+1; section 1 = rows 32..63 -> acc[1], epilogue of rows 0..31 of tile t,
+  // loads for rows 32..63, pieces NP0.. of tile t+1.  One barrier per tile.
+  bool pend_issued = false;                                // the loads of the pending section (rows 32..63 of Tp) are in flight / in xr
+  for (int t = first, it = 0; t < last; ++t, ++it) {
+    int lanem = lane_;
+    asm volatile("" : "+v"(lanem));
+    const bf16_t* ab = planes + (size_t)(it & 1) * 2 * WS_PLANE + (lanem & 31) * WS_PITCH + (lanem >> 5) * 8;
+    bf16x8 ah[2], al;
+    auto a_ptr = [&](int S) {                               // step S of the tile: section S / NS, (tap, k-step) S % NS
+      const int h = S / Sch::NS, s = S % Sch::NS;
+      return ab + toff[s / WS_KSTEPS] + h * 32 * WS_PITCH + (s % WS_KSTEPS) * 16;
+    };
+    auto load_a = [&](int S) {
+      al = *reinterpret_cast<const bf16x8*>(a_ptr(S) + WS_PLANE);
+      ah[S & 1] = *reinterpret_cast<const bf16x8*>(a_ptr(S));
+    };
+    load_a(0);
+    __builtin_amdgcn_sched_barrier(0);
+    const bool doE = t > first;
+    const Tile Tnn = t + 2 < last ? next_tile(Tn) : Tn;       // (clamped: Tn is already the last tile then)
+    const bool edgeT = is_edge(Tn), edgeD = is_edge(Tnn);
+    const bool fast = doE && !is_partial(Tp) && !is_partial(Tc) && !edgeT && !edgeD && Tp.b == Tc.b;
+    if (Tn.b != cur_b) load_consts(Tn.b);
+    xbase_d = row_block(a.x, Tnn.b, a.Lin, Tnn.tile * WS_TM + a.rowmin, WS_C * 4);
+    if constexpr (PRO2) x2base_d = row_block(a.nb_x, Tnn.b, a.Lin, Tnn.tile * WS_TM + a.rowmin, WS_C * 4);
+    aobase_t = const_cast<char*>(row_block(a.a_out, Tn.b, a.Lin, Tn.tile * WS_TM + a.rowmin, WS_C * 2));
+    yb_p = block8(a.y, Tp.b, Tp.tile * WS_TM);
+    yb_c = block8(a.y, Tc.b, Tc.tile * WS_TM);
+    xb_c = block8(a.ep_x, Tc.b, Tc.tile * WS_TM);
+    if constexpr (EP == 4) gb_c = block8(a.ep_g2, Tc.b, Tc.tile * WS_TM);
+    stbase_p = const_cast<char*>(row_block(a.stats, Tp.b, a.ntiles, Tp.tile, WS_C * 8));
+    pl_cur = (it + 1) & 1 ? pl_off + WS_BUF_BYTES : pl_off;
+    asm volatile("" : "+v"(pl_cur));
+    if (doE && !fast) {                                     // pending section of the previous tile, not overlapped
+      drain_vmem();
+      asm volatile("s_nop 15\n\ts_nop 15" : "+v"(acc[1]));
+      epi_plain(std::integral_constant<int, 1>{}, Tp, yb_p, block8(a.ep_x, Tp.b, Tp.tile * WS_TM),
+                EP == 4 ? block8(a.ep_g2, Tp.b, Tp.tile * WS_TM) : nullptr);
+      epi_stats();
+      pend_issued = false;
+    }
+    if (fast) {
+      if (cur_eb != Tc.b) load_ep_consts(Tc.b);
+      if (!pend_issued) {                                   // first overlapped tile behind a plain one
+        xcur = block8(a.ep_x, Tp.b, Tp.tile * WS_TM) + 2 * (16 * WS_C * 4);
+        if constexpr (EP == 4) gcur = block8(a.ep_g2, Tp.b, Tp.tile * WS_TM) + 2 * (16 * WS_C * 4);
+        ws_static_for<0, 16>([&](auto i_c) {
+          epi_load(i_c, xcur, gcur);
+          if constexpr (decltype(i_c)::value == 7) { WSD_STEP16(xcur); if constexpr (EP == 4) WSD_STEP16(gcur); }
+        });
+        drain_vmem();
+      }
+    }
+    // One tile: 2 x SECT single-MFMA asm statements with filler slot f behind statement f of a section.
+    auto tile_body = [&](auto fast_c) {
+      constexpr bool FAST = decltype(fast_c)::value;
+      auto filler = [&](auto sec_c, auto f_c) {
+        constexpr int sec = decltype(sec_c)::value, fs = decltype(f_c)::value;
+        if constexpr (!FAST) return;
+        constexpr int he = sec ^ 1;                         // the section whose accumulator the epilogue reads
+        // running pointers of the three streams: set in the slot in front of a stream's first value,
+        // advanced behind its eighth
+        if constexpr (fs == Sch::SB - 1) { ycur = sec == 0 ? yb_p + 2 * (16 * WS_C * 4) : yb_c; asm volatile("" : "+s"(ycur)); }
+        if constexpr (fs == Sch::LB - 1) {
+          if constexpr (sec == 0) { xcur = xb_c; asm volatile("" : "+s"(xcur)); if constexpr (EP == 4) { gcur = gb_c; asm volatile("" : "+s"(gcur)); } }
+          else { WSD_STEP16(xcur); if constexpr (EP == 4) WSD_STEP16(gcur); }
+        }
+        // ---- epilogue stream: value v enters at slot E0 + v*EII, one level per slot ----
+        if constexpr (fs >= Sch::E0 && fs < Sch::EEND) {
+          ws_static_for<0, 16>([&](auto v_c) {
+            constexpr int v = decltype(v_c)::value, lv = fs - (Sch::E0 + v * Sch::EII);
+            (void)&ssum; (void)&ssq; (void)&y_off;
+            if constexpr (lv >= 0 && lv < Sch::ELV) {
+              if constexpr (lv == 0) {
+                // the previous section issued this value's load(s) in its slot LB + v
+                // (the comment names the registers for tools/wsd_audit.py)
+                constexpr int N = Sch::nwait(sec ^ 1, v);
+                asm volatile("s_waitcnt vmcnt(%0) ; landed v%c1" :: "n"(N), "n"(WSD_XR0 + v) : "memory");
+              }
+              epi_level(std::integral_constant<int, he>{}, v_c, std::integral_constant<int, lv>{});
+            }
+          });
+        }
+        // ---- store burst: values 2k, 2k+1 in slot SB + k ----
+        if constexpr (fs >= Sch::SB && fs < Sch::SB + 8) {
+          constexpr int k2 = 2 * (fs - Sch::SB);
+          epi_store(std::integral_constant<int, k2>{}, ycur);
+          epi_store(std::integral_constant<int, k2 + 1>{}, ycur);
+          if constexpr (k2 == 6) WSD_STEP16(ycur);
+        }
+        if constexpr (sec == 0 && fs == Sch::EEND) epi_stats();
+        // ---- transform stream ----
+        constexpr int np = sec == 0 ? Sch::NP0 : Sch::NP1, jb = sec == 0 ? 0 : Sch::NP0;
+        if constexpr (fs == Sch::T0 - 3) piece_read(jb);
+        if constexpr (fs >= Sch::T0 && fs < Sch::T0 + np * Sch::SUBS) {
+          constexpr int p = (fs - Sch::T0) / Sch::SUBS, k = (fs - Sch::T0) % Sch::SUBS, j = jb + p;
+          if constexpr (PRO2) {
+            if constexpr (k < 3) piece_level(Tn, j, k);
+            if constexpr (k == 3) piece_split(j, 0);
+            if constexpr (k == 4) { piece_split(j, 1); piece_level(Tn, j, 3); }
+            if constexpr (k == 5) piece_split(j, 2);
+            if constexpr (k == Sch::KWH) { piece_write(j, 0); piece_split(j, 3); }
+          } else {
+            if constexpr (k == 0) { piece_level(Tn, j, 0); piece_split(j, 0); }
+            if constexpr (k == 1) piece_split(j, 1);
+            if constexpr (k == 2) piece_split(j, 2);
+            if constexpr (k == Sch::KWH) { piece_write(j, 0); piece_split(j, 3); }
+          }
+          if constexpr (k == Sch::KR && p + 1 < np) piece_read(j + 1);
+          if constexpr (k == Sch::KWL) piece_write(j, 1);
+          if constexpr (k == Sch::KC) piece_cache(Tn, false, j);
+          if constexpr (k == Sch::KD0) dma_piece(Tnn, false, j, 0);
+          if constexpr (PRO2 && k == Sch::KD1) dma_piece(Tnn, false, j, 1);
+        }
+        // ---- loads for the next section's epilogue: rows 32*sec .. of the current tile ----
+        if constexpr (fs >= Sch::LB && fs < Sch::LB + 16) {
+          epi_load(std::integral_constant<int, fs - Sch::LB>{}, xcur, gcur);
+          if constexpr (fs - Sch::LB == 7) { WSD_STEP16(xcur); if constexpr (EP == 4) WSD_STEP16(gcur); }
+        }
+      };
+      // The MFMAs are inline asm so that the weight fragments are AGPR operands where they live; an
+      // accumulate chain needs no wait states; the A fragments come from ds_read (waited for by hipcc,
+      // which sees the operand); an accumulator is read by VALU code from slot E0 of the NEXT section
+      // on (>= 3 MFMAs = 96 cycles behind its last MFMA).
+      ws_static_for<0, 2 * Sch::NS>([&](auto S_c) {
+        constexpr int S = decltype(S_c)::value, sec = S / Sch::NS, s = S % Sch::NS;
+        constexpr int tp = s / WS_KSTEPS, k = s % WS_KSTEPS, sl = S & 1;
+        constexpr bool more = S + 1 < 2 * Sch::NS;
+        __builtin_amdgcn_sched_barrier(0);
+#define WSD_MFMA(A, BC, B) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(acc[sec]) : "v"(A), BC(B))
+#define WSD_SLOT(I) __builtin_amdgcn_sched_barrier(0); \
+        filler(std::integral_constant<int, sec>{}, std::integral_constant<int, 3 * s + (I)>{}); __builtin_amdgcn_sched_barrier(0)
+#define WSD_MFMA_LIT(A, R) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, a[" R "], %0" : "+v"(acc[sec]) : "v"(A))
+        constexpr bool hand = s >= WS_NAGPR_FRAGS && s < WS_NAGPR_FRAGS + WS_NHAND;
+        if constexpr (s == 0) {
+          asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, 0" : "=&v"(acc[sec]) : "v"(al), "a"(Bh[0][0]));
+        } else if constexpr (s < WS_NAGPR_FRAGS) {
+          WSD_MFMA(al, "a", Bh[tp][k]);
+        } else if constexpr (hand) {
+          if constexpr (s == 30) WSD_MFMA_LIT(al, "240:243"); else WSD_MFMA_LIT(al, "248:251");
+        } else {
+          WSD_MFMA(al, "v", Bh[tp][k]);
+        }
+        if constexpr (more) { __builtin_amdgcn_sched_barrier(0); load_a(S + 1); }
+        WSD_SLOT(0);
+        if constexpr (s < WS_NAGPR_FRAGS) {
+          WSD_MFMA(ah[sl], "a", Bl[tp][k]); WSD_SLOT(1);
+          WSD_MFMA(ah[sl], "a", Bh[tp][k]); WSD_SLOT(2);
+        } else if constexpr (hand) {
+          if constexpr (s == 30) { WSD_MFMA_LIT(ah[sl], "244:247"); WSD_SLOT(1); WSD_MFMA_LIT(ah[sl], "240:243"); WSD_SLOT(2); }
+          else { WSD_MFMA_LIT(ah[sl], "252:255"); WSD_SLOT(1); WSD_MFMA_LIT(ah[sl], "248:251"); WSD_SLOT(2); }
+        } else {
+          WSD_MFMA(ah[sl], "v", Bl[tp][k]); WSD_SLOT(1);
+          WSD_MFMA(ah[sl], "v", Bh[tp][k]); WSD_SLOT(2);
+        }
+#undef WSD_MFMA_LIT
+#undef WSD_MFMA
+#undef WSD_SLOT
+      });
+    };
+    if (fast) {
+      tile_body(std::true_type{});
+      pend_issued = true;
+    } else {
+      tile_body(std::false_type{});
+      // MFMA result -> VALU reader wait states (the last MFMA of section 1 has just been issued; acc[0]
+      // has been complete for a whole section, but hipcc knows neither)
+      asm volatile("s_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15" : "+v"(acc[0]), "+v"(acc[1]));
+      epi_plain(std::integral_constant<int, 0>{}, Tc, yb_c, xb_c, gb_c);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // transform of the next tile (masked at the ends of an utterance)
+#pragma unroll
+      for (int j = 0; j < WS_DPW; ++j) {
+        piece_read(j);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) piece_elem(Tn, edgeT, j, q);
+        piece_write(j);
+        piece_cache(Tn, edgeT, j);
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the raw pieces are in registers before their refill
+#pragma unroll
+      for (int j = 0; j < WS_DPW; ++j) dma_piece(Tnn, edgeD, j);
+      pend_issued = false;
+    }
+    colsum_put(it + 1);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();                          // planes[(it+1) & 1] complete; planes[it & 1] free
+    if (t + 1 < last) colsum_out(t + 1, it + 1);
+    Tp = Tc; Tc = Tn; Tn = Tnn;
+  }
+  // ================= tail: rows 32..63 of the last tile =================
+  {
+    drain_vmem();
+    asm volatile("s_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15" : "+v"(acc[0]), "+v"(acc[1]));
+    stbase_p = const_cast<char*>(row_block(a.stats, Tp.b, a.ntiles, Tp.tile, WS_C * 8));
+    epi_plain(std::integral_constant<int, 1>{}, Tp, block8(a.y, Tp.b, Tp.tile * WS_TM), block8(a.ep_x, Tp.b, Tp.tile * WS_TM),
+              EP == 4 ? block8(a.ep_g2, Tp.b, Tp.tile * WS_TM) : nullptr);
+    epi_stats();
+  }
+#undef WS_IDS
+#undef WSD_IMM
+#undef WSD_Q
+#undef WSD_STEP16
+#undef WSD_XR0
+}
+
+template <int NT, int HALO, int PRO, int EP>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) __attribute__((amdgpu_num_vgpr(240)))
+void sa_conv_wsd_kernel(SaConvArgs a, int tiles_per_wg, int total_tiles) {
+  wsd_body<NT, HALO, PRO, EP>(a, tiles_per_wg, total_tiles);
+}
+
+template <int NT, int HALO, int PRO, int EP>
+int launch_wsd(const SaConvArgs& a, hipStream_t st) {
+  typedef WsGeo<128, NT, HALO> G;
+  SaConvArgs args = a;
+  args.ntiles = sa_div_up(a.Lout, G::BM);
+  int omin = 1 << 30, omax = -(1 << 30), wmax = 0;
+  for (int t = 0; t < NT; ++t) {
+    omin = a.taps.off[0][t] < omin ? a.taps.off[0][t] : omin;
+    omax = a.taps.off[0][t] > omax ? a.taps.off[0][t] : omax;
+    wmax = a.taps.widx[0][t] > wmax ? a.taps.widx[0][t] : wmax;
+  }
+  if (omax - omin != HALO) return -22;
+  args.rowmin = omin;
+  args.nrows = G::ROWS;
+  args.wlo_off = (wmax + 1) * G::KSTEPS * 4 * 64;            // fragment units: size of the hi image
+  if ((a.a_out || a.nb_colsum) && (omin > 0 || omax < 0 || (args.ntiles - 1) * G::BM + omin + G::ROWS < a.Lin))
+    return -22;                                             // every input row must be staged by the tile that owns it
+  if ((long)a.B * a.Lin >= (1L << 31) - 64 || (long)a.B * a.Lout >= (1L << 31) - 64) return -22;   // 32-bit row indices in the kernel
+  const size_t lds = 2 * G::BUF_BYTES + (PRO == 2 ? 2 : 1) * G::RAW_BYTES + (PRO == 2 ? 2 * 4 * 128 * 4 : 0);
+  if (lds > 160 * 1024) return -12;
+  auto kern = sa_conv_wsd_kernel<NT, HALO, PRO, EP>;
+  static bool attr_set = false;
+  static int n_cu = 0;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e != hipSuccess) return -(int)e;
+    int dev = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return -19;
+    n_cu = prop.multiProcessorCount;
+    attr_set = true;
+  }
+  const int total = args.ntiles * a.B;
+  const int per = sa_div_up(total, n_cu);
+  const int nwg = sa_div_up(total, per);
+  hipLaunchKernelGGL(kern, dim3(nwg), dim3(256), lds, st, args, per, total);
+  hipError_t e = hipGetLastError();
+  return e == hipSuccess ? 0 : -(int)e;
+}
+
+// which instantiation serves the launch: 0 = none
+int wsd_variant(int dtype, int cin, int cout, int sa, int u, const SaConvArgs* a) {
+  if (dtype != SA_BF16X3 || cin != 128 || cout != 128 || sa != 1 || u != 1) return 0;
+  if (a->ep_mode != 1 && a->ep_mode != 2) return 0;
+  if (!a->ep_x || !a->ep_mean || !a->ep_rstd || !a->stats) return 0;
+  if (a->s1 || a->t1 || a->s2 || a->t2 || a->swish || a->relu || a->pro_stats || a->wscale) return 0;
+  if (a->tile_rows && a->tile_rows != 64) return 0;
+  const int nt = a->taps.ntaps[0];
+  if (nt != 5 && nt != 3) return 0;
+  int omin = 1 << 30, omax = -(1 << 30);
+  for (int t = 0; t < nt; ++t) {
+    omin = a->taps.off[0][t] < omin ? a->taps.off[0][t] : omin;
+    omax = a->taps.off[0][t] > omax ? a->taps.off[0][t] : omax;
+  }
+  const int halo = omax - omin;
+  if (nt == 5 ? halo != 4 : (halo != 4 && halo != 6)) return 0;
+  if (omin > 0 || (omin & 1) || omax < 0) return 0;        // ownership tests work on whole DMA pieces (row pairs)
+  int pro, ep;
+  if (a->nb_x) {
+    if (!a->nb_c1 || !a->nb_c2 || !a->nb_c3) return 0;
+    pro = 2;
+  } else {
+    if (a->a_out || a->nb_colsum) return 0;
+    pro = 0;
+  }
+  if (a->ep_mode == 1) {
+    if (!a->ep_s1 || !a->ep_t1 || a->ep_xp_is_act || a->ep_bstride != 128) return 0;
+    if (a->ep_g2) { if (!a->ep_g2k1 || !a->ep_g2k2 || !a->ep_g2k3) return 0; ep = 4; } else ep = 1;
+  } else {
+    if (a->ep_g2 || a->ep_bstride != 0) return 0;
+    if (a->ep_xp_is_act) { if (!a->ep_s1 || !a->ep_t1) return 0; ep = 3; } else { if (a->ep_s1 || a->ep_t1) return 0; ep = 2; }
+  }
+  // the instantiations the train step needs
+  if (nt == 5 && pro == 2 && ep == 1) return 1;            // encoder.11
+  if (nt == 5 && pro == 2 && ep == 3) return 2;            // sex_classifier.tdnn.0
+  if (nt == 5 && pro == 0 && ep == 4) return 3;            // decoder.0
+  if (nt == 3 && halo == 4 && pro == 2 && ep == 2) return 4;   // sex_classifier.tdnn.3
+  if (nt == 3 && halo == 6 && pro == 2 && ep == 2) return 5;   // sex_classifier.tdnn.6
+  return 0;
+}
+
+}  // namespace
+
+// Does the fused data-gradient kernel serve this launch?  (sa_conv_gemm.hip asks before routing.)
+bool sa_conv_wsd_covers(int dtype, int cin, int cout, int sa, int u, const SaConvArgs* a) {
+  return wsd_variant(dtype, cin, cout, sa, u, a) != 0;
+}
+
+int sa_conv_wsd_dispatch(int cin, int cout, const SaConvArgs* a, hipStream_t st) {
+  switch (wsd_variant(SA_BF16X3, cin, cout, 1, 1, a)) {
+    case 1: return launch_wsd<5, 4, 2, 1>(*a, st);
+    case 2: return launch_wsd<5, 4, 2, 3>(*a, st);
+    case 3: return launch_wsd<5, 4, 0, 4>(*a, st);
+    case 4: return launch_wsd<3, 4, 2, 2>(*a, st);
+    case 5: return launch_wsd<3, 6, 2, 2>(*a, st);
+    default: return -38;
+  }
+}
