@@ -120,6 +120,11 @@ class Brain:
         # hip_graph: capture the whole train step (forward, losses, backward, clip, Adam) in a
         # hipGraph per batch shape and replay it (single process; see SexAnonymizationTraining)
         self.hip_graph = bool(run_opts.get("hip_graph", False)) and self.device.type == "cuda"
+        # gc_freeze (default on): fit() settles the interpreter heap after its first steps
+        # (settle_python_heap: gc.collect + gc.freeze).  gc.freeze() is process-global -- cyclic garbage
+        # among the objects alive at that point is never collected afterwards -- so a host application
+        # that embeds the Brain can switch it off
+        self.gc_freeze = bool(run_opts.get("gc_freeze", True))
         self.distributed_launch = bool(run_opts.get("distributed_launch", sdist.is_distributed()))
         self.modules = torch.nn.ModuleDict(modules or {})
         self.opt_class = opt_class
@@ -265,7 +270,7 @@ class Brain:
                 self.step += 1
                 loss = self.fit_batch(batch)
                 self.avg_train_loss = self.update_average(loss, self.avg_train_loss)
-                if self.step == self.GC_FREEZE_STEP and not self.__dict__.get("_gc_frozen"):
+                if self.gc_freeze and self.step == self.GC_FREEZE_STEP and not self.__dict__.get("_gc_frozen"):
                     settle_python_heap()
                     self._gc_frozen = True
             self.avg_train_loss = float(self.avg_train_loss)          # the epoch's one host read
@@ -357,6 +362,21 @@ class SexAnonymizationTraining(Brain):
                     lr, _, _ = ext.classify_batch_feats(reconstructed_speech.detach())
                 self.sex_classification_acc_extern_orig.append(lo.unsqueeze(0), sex_label.unsqueeze(0), n)
                 self.sex_classification_acc_extern.append(lr.unsqueeze(0), sex_label.unsqueeze(0), n)
+            if asr_brain is not None:
+                # reference :156-163 (VALID) / :164-173 (TEST, there together with beam search and WER,
+                # which stay out of scope): cosine similarity of the frozen recogniser's encoder outputs
+                # on the reconstructed and on the original features, one value per utterance ->
+                # "Utility_Retention", the max_key of save_and_keep_only
+                from . import ops
+                tokens_bos, _ = batch.tokens_bos
+                with torch.no_grad():
+                    recon_enc, _ = asr_brain.get_predictions(reconstructed_speech.detach(), wav_lens, tokens_bos,
+                                                             batch, eval=True, do_ctc=False)
+                    orig_enc, _ = asr_brain.get_predictions(feats, wav_lens, tokens_bos, batch, eval=True,
+                                                            do_ctc=False)
+                    nb = recon_enc.shape[0]
+                    self.utility_similarity_aggregator.append(
+                        ops.cosine_rows(recon_enc.reshape(nb, -1), orig_enc.reshape(nb, -1)))
         return loss
 
     def apply_epoch_schedule(self):
@@ -406,10 +426,19 @@ class SexAnonymizationTraining(Brain):
         wavs, lens = batch.sig
         nrm = self.modules["normalize"] if "normalize" in self.modules else None
         upd = nrm is not None and hp.epoch_counter.current < getattr(nrm, "update_until_epoch", 0)
+        # what the captured step does also depends on host state: the target-token shape (utility
+        # branch), and -- under the epoch-parity schedule -- on whether a frozen parameter already has
+        # Adam moments (torch 1.10's zero-filled gradients keep such a parameter moving, a stateless one
+        # stays out of the update: _zero_grads_of_frozen), so both are part of the key
+        st = self.optimizer.state if self.optimizer is not None else {}
+        params = list(self.modules.ConvAE.parameters())
+        tok = batch.tokens_bos[0]
         return (tuple(wavs.shape), str(wavs.dtype), hp.model_type, float(hp.recon_loss_weight),
                 float(hp.sex_loss_weight), float(hp.utility_loss_weight),
                 float(getattr(hp, "confusion_loss_weight", 0.0)), bool(upd),
-                tuple(p.requires_grad for p in self.modules.ConvAE.parameters()))
+                tuple(p.requires_grad for p in params),
+                tuple(bool(st.get(p)) for p in params if not p.requires_grad),
+                tuple(tok.shape), getattr(self, "asr_brain", None) is not None)
 
     def _step_core(self, batch):
         predictions = self.compute_forward(batch, Stage.TRAIN)
@@ -439,7 +468,12 @@ class SexAnonymizationTraining(Brain):
             wavs, lens = batch.sig
             ent["wav"], ent["lens"] = wavs.clone(), lens.clone()
             ent["gender"] = batch.gender.clone()
-            ent["batch"] = Batch(ent["wav"], ent["lens"], ent["gender"])
+            # the target tokens are part of the static batch (the utility branch decodes them); the
+            # utterance ids ride along for the hooks that log them
+            tok, tok_lens = batch.tokens_bos
+            ent["tok"], ent["tok_lens"] = tok.clone(), tok_lens.clone()
+            ent["batch"] = Batch(ent["wav"], ent["lens"], ent["gender"], tokens_bos=ent["tok"], ids=batch.id)
+            ent["batch"].tokens_bos = (ent["tok"], ent["tok_lens"])
             torch.cuda.synchronize()
             self.nonfinite_count += self._poll_nonfinite(wait=True)      # nothing pending across the capture
             g = torch.cuda.CUDAGraph()
@@ -452,6 +486,9 @@ class SexAnonymizationTraining(Brain):
         ent["wav"].copy_(wavs, non_blocking=True)
         ent["lens"].copy_(lens, non_blocking=True)
         ent["gender"].copy_(batch.gender, non_blocking=True)
+        ent["tok"].copy_(batch.tokens_bos[0], non_blocking=True)
+        ent["tok_lens"].copy_(batch.tokens_bos[1], non_blocking=True)
+        ent["batch"].id = batch.id
         bad = self._poll_nonfinite()                        # counter copies of earlier replays
         if bad:
             self.nonfinite_count += bad

@@ -40,6 +40,31 @@
 // a tile body, loaded registers untouched between load and wait).
 #include "sa_conv_ws_common.h"
 
+// -DSA_WSD_ABL=<mask>: timing-only ablation builds (tools/wsd_ablate.py; WRONG results, never shipped):
+//   1 no epilogue stream (waits, levels, stores, loads, statistics)   2 no transform stream (incl. refill DMA)
+//   4 no MFMA   8 no counted waits   16 no epilogue loads and waits   32 no epilogue stores
+#ifndef SA_WSD_ABL
+#define SA_WSD_ABL 0
+#endif
+
+// -DSA_WSD_STAMPS: diagnostic build (tools/wsd_stamps.py): s_memtime at the section boundaries of one
+// workgroup's wave 0; no stamp exists in the normal build.
+#ifdef SA_WSD_STAMPS
+__device__ unsigned long long sa_wsd_dbg[64 * 16];
+#define WSD_STAMP(it, i) do { if (lane_ == 0 && wave_ == 0 && blockIdx.x == 7 && (it) < 64) { \
+  unsigned long long t_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); \
+  sa_wsd_dbg[(it) * 16 + (i)] = t_; } } while (0)
+#define WSD_STAMP_RT(it, i) do { if (lane_ == 0 && wave_ == 0 && blockIdx.x == 7 && (it) < 64) { \
+  unsigned long long t_; asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); \
+  sa_wsd_dbg[(it) * 16 + (i)] = t_; } } while (0)
+extern "C" int sa_wsd_dbg_read(unsigned long long* out) {
+  return -(int)hipMemcpyFromSymbol(out, HIP_SYMBOL(sa_wsd_dbg), sizeof(sa_wsd_dbg));
+}
+#else
+#define WSD_STAMP(it, i)
+#define WSD_STAMP_RT(it, i)
+#endif
+
 namespace {
 
 // ---- the slot schedule of one instantiation (compile-time; shared by the filler and the wait counts) ----
@@ -59,7 +84,9 @@ struct WsdSched {
   static constexpr int EII = EP_ == 1 || EP_ == 4 ? 3 : EP_ == 3 ? 2 : 1; // slots between two values
   static constexpr int ELV = EP_ == 1 ? 11 : EP_ == 4 ? 13 : EP_ == 3 ? 9 : 3;  // dependence levels of a value
   static constexpr int LVG = EP_ == 1 ? 9 : EP_ == 4 ? 11 : EP_ == 3 ? 5 : 1;   // level that leaves the final value in the load's register
-  static constexpr int E0 = 3;                            // first epilogue slot (MFMA -> VALU distance)
+  // first epilogue slot (>= 3: MFMA -> VALU distance), chosen so that the heavier levels of the three
+  // values in flight do not share a slot with the step's A-fragment reads
+  static constexpr int E0 = EP_ == 4 ? 5 : 3;             // (EP 1 at 4: measured slower, 2568 against 2316 cycles to the store burst)
   static constexpr int EEND = E0 + 15 * EII + ELV;        // first slot behind the epilogue arithmetic: the statistics
   // Vector-memory loads retire in order among themselves (LDS-DMA included) and stores among themselves,
   // but NOT loads relative to stores: a counted vmcnt(N) is exact only while every operation younger
@@ -96,11 +123,12 @@ struct WsdSched {
   static constexpr int nwait(int s, int v) { return (15 - v) * LPV + dma_after(s, LB + v); }
 };
 
-// LDS-DMA piece with the destination formed in the statement: M0 = base + immediate (s_add_u32 writes SCC)
+// LDS-DMA piece with the destination formed in the statement: M0 = base + immediate (s_add_u32 writes
+// SCC).  M0 is not saved and restored around it: hipcc itself neither reads nor writes M0 anywhere in this
+// kernel (gfx950 LDS instructions do not use it; tools/wsd_audit.py checks the ISA for a compiler "m0").
 __device__ static inline void wsd_dma16i(const void* gbase, unsigned voff, unsigned lds_base, int imm) {
-  unsigned keep;
-  asm volatile("s_mov_b32 %0, m0\n\ts_add_u32 m0, %3, %4\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
-               : "=&s"(keep) : "v"(voff), "s"(gbase), "s"(lds_base), "n"(imm) : "memory", "scc");
+  asm volatile("s_add_u32 m0, %2, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1"
+               :: "v"(voff), "s"(gbase), "s"(lds_base), "n"(imm) : "memory", "scc");
 }
 
 // The stored-tensor values of the pending section (and the second gradient, EP 4) are loaded by asm a
@@ -117,7 +145,7 @@ __device__ static inline void wsd_dma16i(const void* gbase, unsigned voff, unsig
 // the reserved registers.
 #define WSD_XR0 240
 template <int NT, int HALO, int PRO, int EP>
-__device__ __forceinline__ void wsd_body(const SaConvArgs& a, int tiles_per_wg, int total_tiles) {
+__device__ __forceinline__ void wsd_body(const SaConvArgs& a, int bcost, int total_tiles) {
   typedef WsGeo<128, NT, HALO> G;
   typedef WsdSched<NT, HALO, PRO, EP> Sch;
   constexpr int WS_C = 128, WS_TM = 64, WS_KSTEPS = G::KSTEPS, WS_PITCH = G::PITCH, RPP = G::RPP, LPR = G::LPR;
@@ -140,9 +168,22 @@ __device__ __forceinline__ void wsd_body(const SaConvArgs& a, int tiles_per_wg, 
   asm volatile("" : "+s"(raw_lds_w));
   const int tid = threadIdx.x, lane_ = tid & 63;
   const int wave_ = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int first = blockIdx.x * tiles_per_wg;
-  int last = first + tiles_per_wg;
-  if (last > total_tiles) last = total_tiles;
+  // This workgroup's contiguous tile range.  Tiles are not equally expensive: the few tiles around the
+  // end of an utterance run un-overlapped (about `bcost` tiles' worth of extra time per utterance end,
+  // measured: tools/wsd_stamps.py), and the launch ends with its slowest workgroup -- so the ranges are
+  // cut at equal COST, an utterance counting ntiles + bcost.
+  int first, last;
+  {
+    const unsigned long long U = (unsigned long long)a.ntiles + (unsigned)bcost;
+    const unsigned long long ctot = (unsigned long long)(total_tiles / a.ntiles) * U;
+    auto inv = [&](unsigned long long c) {                  // first tile whose cumulative cost reaches c
+      const unsigned long long k = c / U, r = c - k * U;
+      const unsigned long long t = k * (unsigned)a.ntiles + (r < (unsigned)a.ntiles ? r : (unsigned)a.ntiles);
+      return (int)(t < (unsigned)total_tiles ? t : (unsigned)total_tiles);
+    };
+    first = inv(ctot * blockIdx.x / gridDim.x);
+    last = blockIdx.x + 1 == gridDim.x ? total_tiles : inv(ctot * (blockIdx.x + 1) / gridDim.x);
+  }
   if (first >= last) return;
 
   // ---- the weights: this wave's 32 output columns, all taps / channels, hi and lo images ----
@@ -182,8 +223,8 @@ __device__ __forceinline__ void wsd_body(const SaConvArgs& a, int tiles_per_wg, 
       __builtin_amdgcn_sched_barrier(0);
     }
   }
-  float bv = a.bias ? a.bias[wave_ * 32 + (lane_ & 31)] : 0.0f;
-  unsigned mask_bits = a.nb_relu_mask ? 0u : 0xff800000u;       // y > -inf: no mask, no branch in the slot (uniform: a scalar register)
+  // (data gradients carry no bias: wsd_variant() sends a launch with one to the one-tile kernel)
+  constexpr bool MASK = PRO2 && EP != 1;                    // ReLU mask of the BatchNorm blocks' prologue (wsd_variant() checks)
   const bool has_stats = a.stats != nullptr, has_ao = a.a_out != nullptr;
 
   // ---- lane constants of the filler slots (opaque: hipcc keeps THESE and derives per-slot addresses
@@ -195,21 +236,40 @@ __device__ __forceinline__ void wsd_body(const SaConvArgs& a, int tiles_per_wg, 
   unsigned pl_off = (row0 * WS_PITCH + cq_ * 4) * 2;       // byte offset in an operand plane: + j*4*RPP*PITCH*2
   unsigned ao_off = (row0 * WS_C + cq_ * 4) * 2;           // byte offset in the a_out row block: + j*4*RPP*C*2
   unsigned y_off = ((4 * half_) * WS_C + wave_ * 32 + l31_) * 4;   // byte offset in a [64][128] fp32 row block: + ro*512
-  asm volatile("" : "+s"(mask_bits));
-  const float mask_thr = __uint_as_float(mask_bits);
-  asm volatile("" : "+v"(bv), "+v"(row0), "+v"(raw_off), "+v"(pl_off), "+v"(ao_off), "+v"(y_off));
+  asm volatile("" : "+v"(row0), "+v"(raw_off), "+v"(pl_off), "+v"(ao_off), "+v"(y_off));
 
 #define WS_IDS int lane = lane_, wave = wave_; asm volatile("" : "+v"(lane), "+s"(wave)); (void)wave; (void)lane
 
-  struct Tile { int b, tile; };
-  auto tile_of = [&](int t) { Tile r; r.b = t / a.ntiles; r.tile = t - r.b * a.ntiles; return r; };
-  auto next_tile = [&](Tile T) { Tile r; const bool wrap = T.tile + 1 == a.ntiles; r.b = wrap ? T.b + 1 : T.b; r.tile = wrap ? 0 : T.tile + 1; return r; };
-  // rows outside the utterance among the staged ones, or the trailing rows it owns beyond its 64
-  auto is_edge = [&](Tile T) {
-    const int g0 = T.tile * WS_TM + a.rowmin;
-    return g0 < 0 || g0 + WS_ROWS > a.Lin || T.tile == a.ntiles - 1;
+  // a tile = (utterance, tile of the utterance) + its first staged input row and first output row in the
+  // [B*Lin] / [B*Lout] row spaces, advanced incrementally (the per-tile bookkeeping is scalar code in
+  // front of the tile body: nothing overlaps it)
+  struct Tile { int b, tile, irow, orow; };
+  auto tile_of = [&](int t) {
+    Tile r; r.b = t / a.ntiles; r.tile = t - r.b * a.ntiles;
+    r.irow = r.b * a.Lin + r.tile * WS_TM + a.rowmin; r.orow = r.b * a.Lout + r.tile * WS_TM;
+    return r;
   };
-  auto is_partial = [&](Tile T) { return T.tile * WS_TM + WS_TM > a.Lout; };
+  const int iwrap = a.Lin - (a.ntiles - 1) * WS_TM, owrap = a.Lout - (a.ntiles - 1) * WS_TM;
+  auto next_tile = [&](Tile T) {
+    Tile r; const bool wrap = T.tile + 1 == a.ntiles;
+    r.b = wrap ? T.b + 1 : T.b; r.tile = wrap ? 0 : T.tile + 1;
+    r.irow = T.irow + (wrap ? iwrap : WS_TM); r.orow = T.orow + (wrap ? owrap : WS_TM);
+    return r;
+  };
+  // rows outside the utterance among the staged ones, or the trailing rows it owns beyond its 64:
+  // tile*64 + rowmin < 0, tile*64 + rowmin + ROWS > Lin, or the last tile -- two thresholds on the tile index
+  const int edge_lo = a.rowmin < 0 ? (-a.rowmin + WS_TM - 1) / WS_TM : 0;
+  int edge_hi = (a.Lin - WS_ROWS - a.rowmin) >> 6;          // (floor)
+  if (edge_hi > a.ntiles - 2) edge_hi = a.ntiles - 2;
+  const int part_hi = (a.Lout - WS_TM) >> 6;
+  auto is_edge = [&](Tile T) { return T.tile < edge_lo || T.tile > edge_hi; };
+  auto is_partial = [&](Tile T) { return T.tile > part_hi; };
+  // an iteration is overlapped when the previous, the current and the next two tiles are interior tiles
+  // of ONE utterance: tile c-1 .. c+2 with c in [fast_lo, fast_hi]
+  const int fast_lo = edge_lo > 2 ? edge_lo - 1 : 1;
+  int fast_hi = edge_hi - 2;
+  if (fast_hi > part_hi) fast_hi = part_hi;
+  if (fast_hi > a.ntiles - 3) fast_hi = a.ntiles - 3;
 
   // ---- constants: prologue coefficients per (utterance | -, channel quad); epilogue per column ----
   float k1[4], k2[4], k3[4];
@@ -244,8 +304,8 @@ __device__ __forceinline__ void wsd_body(const SaConvArgs& a, int tiles_per_wg, 
   // ---- uniform per-tile bases (set once per iteration, opaque) ----
   const char* xbase_d = nullptr; const char* x2base_d = nullptr;    // rows of the DMA tile (x, nb_x)
   char* aobase_t = nullptr;                                          // a_out rows of the transform tile
-  auto row_block = [&](const void* p, int b, int L, int row, int row_bytes) {
-    const char* r = reinterpret_cast<const char*>(p) + (long)(b * L + row) * row_bytes;   // B*L rows < 2^31 (checked at launch)
+  auto row_ptr = [&](const void* p, int row, int row_bytes) {                  // (B*L rows < 2^31: checked at launch)
+    const char* r = reinterpret_cast<const char*>(p) + (long)row * row_bytes;
     asm volatile("" : "+s"(r));
     return r;
   };
@@ -254,8 +314,8 @@ __device__ __forceinline__ void wsd_body(const SaConvArgs& a, int tiles_per_wg, 
   // q = 2h + (i >> 3), immediate ((i >> 2) & 1 ? 0 : -4096) + (i & 3) * 512.  The slots walk the values in
   // order, so each stream (y stores, ep_x loads, ep_g2 loads) keeps ONE running pointer, advanced by 16
   // rows after every eighth value.
-  auto block8 = [&](const void* p, int b, int row) {       // row 8 of the tile's row block
-    const char* r = reinterpret_cast<const char*>(p) + ((long)(b * a.Lout + row) * WS_C + 8 * WS_C) * 4;
+  auto block8 = [&](const void* p, Tile T) {               // row 8 of the tile's output row block
+    const char* r = reinterpret_cast<const char*>(p) + ((long)T.orow * WS_C + 8 * WS_C) * 4;
     asm volatile("" : "+s"(r));
     return r;
   };
@@ -278,8 +338,7 @@ __device__ __forceinline__ void wsd_body(const SaConvArgs& a, int tiles_per_wg, 
       }
     } else {
       WS_IDS;
-      const int g0 = T.tile * WS_TM + a.rowmin;
-      int g = g0 + RPP * i + lane / LPR;
+      int g = T.tile * WS_TM + a.rowmin + RPP * i + lane / LPR;
       g = g < 0 ? 0 : (g >= a.Lin ? a.Lin - 1 : g);        // rows outside the utterance: any valid address (zeroed in the transform)
       const size_t off = ((size_t)T.b * a.Lin + g) * (WS_C * 4) + (lane % LPR) * 16;
       ws_dma16(reinterpret_cast<const char*>(a.x) + off, raw_lds + i * 1024);
@@ -327,7 +386,7 @@ __device__ __forceinline__ void wsd_body(const SaConvArgs& a, int tiles_per_wg, 
     if constexpr (PRO2) {
       const float y = vy[0][q];
       v = fmaf(k1[q], v, fmaf(k2[q], y, k3[q]));
-      v = y > mask_thr ? v : 0.0f;
+      if constexpr (MASK) v = y > 0.0f ? v : 0.0f;
       if (owns(T, edge, j)) csum[q] += v;
     }
     if (edge) {                                            // rows outside the utterance are zero operands
@@ -348,8 +407,9 @@ __device__ __forceinline__ void wsd_body(const SaConvArgs& a, int tiles_per_wg, 
       } else {
         if (lv == 0) z[q] = fmaf(k2[q], vy[0][q], k3[q]);
         if (lv == 1) f[q] = fmaf(k1[q], vx[0][q], z[q]);
-        if (lv == 2) f[q] = vy[0][q] > mask_thr ? f[q] : 0.0f;
-        if (lv == 3) { if (owns(T, false, j)) csum[q] += f[q]; }
+        if (lv == 2) { if constexpr (MASK) f[q] = vy[0][q] > 0.0f ? f[q] : 0.0f; }
+        // (asm: hipcc otherwise sinks the sums of all pieces into the slot that folds them)
+        if (lv == 3) { if (owns(T, false, j)) asm volatile("v_add_f32 %0, %0, %1" : "+v"(csum[q]) : "v"(f[q])); }
       }
     }
   };
@@ -385,24 +445,35 @@ __device__ __forceinline__ void wsd_body(const SaConvArgs& a, int tiles_per_wg, 
     if constexpr (PRO2) {
       if (a.nb_colsum) {
         float* colred = reinterpret_cast<float*>(raw + 2 * WS_RAW_BYTES) + (size_t)(it & 1) * 4 * WS_C;
+        f32x4 v;
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          const float v = csum[q] + __int_as_float(__builtin_amdgcn_ds_bpermute((lane_ ^ 32) * 4, __float_as_int(csum[q])));
-          if (lane_ < 32) colred[wave_ * WS_C + (lane_ & 31) * 4 + q] = v;
+        for (int q = 0; q < 4; ++q) {                      // lanes l and l + 32 hold the same channel quad
+          const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(csum[q]), __float_as_uint(csum[q]), false, false);
+          v[q] = __uint_as_float(r[0]) + __uint_as_float(r[1]);
         }
+        if (lane_ < 32) *reinterpret_cast<f32x4*>(colred + wave_ * WS_C + (lane_ & 31) * 4) = v;
       }
 #pragma unroll
       for (int q = 0; q < 4; ++q) csum[q] = 0.0f;
     }
   };
-  auto colsum_out = [&](int t, int it) {                    // after the barrier that follows colsum_put(it)
+  // (in two halves: the LDS reads, and -- a slot or more later in an overlapped body -- the sum and store)
+  float cso[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+  auto colsum_rd = [&](int it) {                            // after the barrier that follows colsum_put(it)
     if constexpr (PRO2) {
       if (a.nb_colsum && tid < WS_C) {
         const float* colred = reinterpret_cast<const float*>(raw + 2 * WS_RAW_BYTES) + (size_t)(it & 1) * 4 * WS_C;
-        a.nb_colsum[(size_t)t * WS_C + tid] = (colred[tid] + colred[WS_C + tid]) + (colred[2 * WS_C + tid] + colred[3 * WS_C + tid]);
+#pragma unroll
+        for (int w_ = 0; w_ < 4; ++w_) cso[w_] = colred[w_ * WS_C + tid];
       }
     }
   };
+  auto colsum_wr = [&](int t) {
+    if constexpr (PRO2) {
+      if (a.nb_colsum && tid < WS_C) a.nb_colsum[(size_t)t * WS_C + tid] = (cso[0] + cso[1]) + (cso[2] + cso[3]);
+    }
+  };
+  auto colsum_out = [&](int t, int it) { colsum_rd(it); colsum_wr(t); };
 
   // ---- epilogue: one accumulator register = one value (row ro + 4*half, this lane's column) ----
   f32x16 acc[2];
@@ -422,7 +493,7 @@ __device__ __forceinline__ void wsd_body(const SaConvArgs& a, int tiles_per_wg, 
 #define WSD_X_FMA(dst, m, c) asm volatile("v_fma_f32 %0, v%c3, %1, %2" : "=v"(dst) : "v"(m), "v"(c), "n"(WSD_XR0 + i))
 #define WSD_X_SUB(dst, c) asm volatile("v_sub_f32 %0, v%c2, %1" : "=v"(dst) : "v"(c), "n"(WSD_XR0 + i))
 #define WSD_X_SETMUL(a_, b_) asm volatile("v_mul_f32 v%c2, %0, %1" :: "v"(a_), "v"(b_), "n"(WSD_XR0 + i))
-#define WSD_X_SETADD(a_, b_) asm volatile("v_add_f32 v%c2, %0, %1" :: "v"(a_), "v"(b_), "n"(WSD_XR0 + i))
+#define WSD_X_SET(a_) asm volatile("v_mov_b32 v%c1, %0" :: "v"(a_), "n"(WSD_XR0 + i))
 #define WSD_G2_READ(dst) asm volatile("v_accvgpr_read_b32 %0, a%c1" : "=v"(dst) : "n"(WSD_XR0 + i))
     // the last level that needs x writes the final value over it (in its reserved register): the store burst and the
     // statistics read it there
@@ -432,7 +503,7 @@ __device__ __forceinline__ void wsd_body(const SaConvArgs& a, int tiles_per_wg, 
       if constexpr (lv == 2) ew[r] = __builtin_amdgcn_exp2f(ew[r]);
       if constexpr (lv == 3) ew[r] = 1.0f + ew[r];
       if constexpr (lv == 4) es[r] = __builtin_amdgcn_rcpf(ew[r]);
-      if constexpr (lv == 5) { et[r] = 1.0f - es[r]; eg[r] = acc[h][i] + bv; }
+      if constexpr (lv == 5) { et[r] = 1.0f - es[r]; eg[r] = acc[h][i]; }
       if constexpr (lv == 6) et[r] = fmaf(ez[r], et[r], 1.0f);
       if constexpr (lv == 7) es[r] = es[r] * et[r];
       if constexpr (lv == 8) WSD_X_SUB(exn[r], emu);
@@ -443,11 +514,11 @@ __device__ __forceinline__ void wsd_body(const SaConvArgs& a, int tiles_per_wg, 
       if constexpr (lv == 1) ew[r] = ez[r] * NL2E;
       if constexpr (lv == 2) ew[r] = __builtin_amdgcn_exp2f(ew[r]);
       if constexpr (lv == 3) ew[r] = 1.0f + ew[r];
-      if constexpr (lv == 4) es[r] = __builtin_amdgcn_rcpf(ew[r]);
+      if constexpr (lv == 4) { es[r] = __builtin_amdgcn_rcpf(ew[r]); WSD_G2_READ(exn[r]); }
       if constexpr (lv == 5) { et[r] = 1.0f - es[r]; ea[r] = ez[r] * es[r]; }
-      if constexpr (lv == 6) { et[r] = fmaf(ez[r], et[r], 1.0f); ea[r] = fmaf(gk2, ea[r], gk3); WSD_G2_READ(ew[r]); }
-      if constexpr (lv == 7) { es[r] = es[r] * et[r]; ea[r] = fmaf(gk1, ew[r], ea[r]); }
-      if constexpr (lv == 8) eg[r] = acc[h][i] + bv;
+      if constexpr (lv == 6) { et[r] = fmaf(ez[r], et[r], 1.0f); ea[r] = fmaf(gk2, ea[r], gk3); }
+      if constexpr (lv == 7) { es[r] = es[r] * et[r]; ea[r] = fmaf(gk1, exn[r], ea[r]); }
+      if constexpr (lv == 8) eg[r] = acc[h][i];
       if constexpr (lv == 9) eg[r] = eg[r] + ea[r];
       if constexpr (lv == 10) WSD_X_SUB(exn[r], emu);
       if constexpr (lv == 11) { WSD_X_SETMUL(eg[r], es[r]); exn[r] = exn[r] * ers; }
@@ -458,19 +529,19 @@ __device__ __forceinline__ void wsd_body(const SaConvArgs& a, int tiles_per_wg, 
       if constexpr (lv == 2) ew[r] = __builtin_amdgcn_exp2f(ew[r]);
       if constexpr (lv == 3) ew[r] = 1.0f + ew[r];
       if constexpr (lv == 4) es[r] = __builtin_amdgcn_rcpf(ew[r]);
-      if constexpr (lv == 5) { ea[r] = ez[r] * es[r]; WSD_X_SETADD(acc[h][i], bv); }
+      if constexpr (lv == 5) { ea[r] = ez[r] * es[r]; WSD_X_SET(acc[h][i]); }
       if constexpr (lv == 6) exn[r] = ea[r] - emu;
       if constexpr (lv == 7) { exn[r] = exn[r] * ers; WSD_ACC_SUM(); }
       if constexpr (lv == 8) WSD_ACC_SQ();
     } else {
       if constexpr (lv == 0) WSD_X_SUB(exn[r], emu);
-      if constexpr (lv == 1) { WSD_X_SETADD(acc[h][i], bv); exn[r] = exn[r] * ers; }
+      if constexpr (lv == 1) { WSD_X_SET(acc[h][i]); exn[r] = exn[r] * ers; }
       if constexpr (lv == 2) { WSD_ACC_SUM(); WSD_ACC_SQ(); }
     }
 #undef WSD_X_FMA
 #undef WSD_X_SUB
 #undef WSD_X_SETMUL
-#undef WSD_X_SETADD
+#undef WSD_X_SET
 #undef WSD_G2_READ
 #undef WSD_ACC_SUM
 #undef WSD_ACC_SQ
@@ -539,14 +610,14 @@ __device__ __forceinline__ void wsd_body(const SaConvArgs& a, int tiles_per_wg, 
   for (int q = 0; q < 4; ++q) csum[q] = 0.0f;
   {
     const bool ec = is_edge(Tc), en = is_edge(Tn);
-    xbase_d = row_block(a.x, Tc.b, a.Lin, Tc.tile * WS_TM + a.rowmin, WS_C * 4);
-    if constexpr (PRO2) x2base_d = row_block(a.nb_x, Tc.b, a.Lin, Tc.tile * WS_TM + a.rowmin, WS_C * 4);
-    aobase_t = const_cast<char*>(row_block(a.a_out, Tc.b, a.Lin, Tc.tile * WS_TM + a.rowmin, WS_C * 2));
+    xbase_d = row_ptr(a.x, Tc.irow, WS_C * 4);
+    if constexpr (PRO2) x2base_d = row_ptr(a.nb_x, Tc.irow, WS_C * 4);
+    aobase_t = const_cast<char*>(row_ptr(a.a_out, Tc.irow, WS_C * 2));
     pl_cur = pl_off;
 #pragma unroll
     for (int j = 0; j < WS_DPW; ++j) dma_piece(Tc, ec, j);
-    xbase_d = row_block(a.x, Tn.b, a.Lin, Tn.tile * WS_TM + a.rowmin, WS_C * 4);
-    if constexpr (PRO2) x2base_d = row_block(a.nb_x, Tn.b, a.Lin, Tn.tile * WS_TM + a.rowmin, WS_C * 4);
+    xbase_d = row_ptr(a.x, Tn.irow, WS_C * 4);
+    if constexpr (PRO2) x2base_d = row_ptr(a.nb_x, Tn.irow, WS_C * 4);
     load_consts(Tc.b);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #pragma unroll
@@ -570,6 +641,9 @@ __device__ __forceinline__ void wsd_body(const SaConvArgs& a, int tiles_per_wg, 
   // rows 32..63 of tile t-1 (acc[1]), the loads for the epilogue of rows 0..31 of tile t, the transform
   // of pieces 0..NP0-1 of tile t+1; section 1 = rows 32..63 -> acc[1], epilogue of rows 0..31 of tile t,
   // loads for rows 32..63, pieces NP0.. of tile t+1.  One barrier per tile.
+  yb_c = block8(a.y, Tc);
+  bool cs_pending = false;
+  bool ptr_step = false;                                   // the per-tile pointers can be advanced by their strides
   bool pend_issued = false;                                // the loads of the pending section (rows 32..63 of Tp) are in flight / in xr
   for (int t = first, it = 0; t < last; ++t, ++it) {
     int lanem = lane_;
@@ -584,36 +658,54 @@ __device__ __forceinline__ void wsd_body(const SaConvArgs& a, int tiles_per_wg, 
       al = *reinterpret_cast<const bf16x8*>(a_ptr(S) + WS_PLANE);
       ah[S & 1] = *reinterpret_cast<const bf16x8*>(a_ptr(S));
     };
+    // column sums of the tile transformed by the previous iteration (= this one's tile): summed over the
+    // waves and stored by 128 threads -- in the first slots of an overlapped body, else here
+    WSD_STAMP(it, 8);
     load_a(0);
     __builtin_amdgcn_sched_barrier(0);
     const bool doE = t > first;
+    const bool fast = doE && Tc.tile >= fast_lo && Tc.tile <= fast_hi;
     const Tile Tnn = t + 2 < last ? next_tile(Tn) : Tn;       // (clamped: Tn is already the last tile then)
-    const bool edgeT = is_edge(Tn), edgeD = is_edge(Tnn);
-    const bool fast = doE && !is_partial(Tp) && !is_partial(Tc) && !edgeT && !edgeD && Tp.b == Tc.b;
+    const bool edgeT = is_edge(Tn), edgeD = is_edge(Tnn);   // (plain iterations only)
+    WSD_STAMP(it, 9);
     if (Tn.b != cur_b) load_consts(Tn.b);
-    xbase_d = row_block(a.x, Tnn.b, a.Lin, Tnn.tile * WS_TM + a.rowmin, WS_C * 4);
-    if constexpr (PRO2) x2base_d = row_block(a.nb_x, Tnn.b, a.Lin, Tnn.tile * WS_TM + a.rowmin, WS_C * 4);
-    aobase_t = const_cast<char*>(row_block(a.a_out, Tn.b, a.Lin, Tn.tile * WS_TM + a.rowmin, WS_C * 2));
-    yb_p = block8(a.y, Tp.b, Tp.tile * WS_TM);
-    yb_c = block8(a.y, Tc.b, Tc.tile * WS_TM);
-    xb_c = block8(a.ep_x, Tc.b, Tc.tile * WS_TM);
-    if constexpr (EP == 4) gb_c = block8(a.ep_g2, Tc.b, Tc.tile * WS_TM);
-    stbase_p = const_cast<char*>(row_block(a.stats, Tp.b, a.ntiles, Tp.tile, WS_C * 8));
+    yb_p = yb_c;                                           // (the previous iteration's current tile)
+    if (fast && ptr_step) {
+      // every tile involved is one tile further along its utterance: constant strides, no multiplies
+      xbase_d += WS_TM * WS_C * 4; asm volatile("" : "+s"(xbase_d));
+      if constexpr (PRO2) { x2base_d += WS_TM * WS_C * 4; asm volatile("" : "+s"(x2base_d)); }
+      aobase_t += WS_TM * WS_C * 2; asm volatile("" : "+s"(aobase_t));
+      yb_c += WS_TM * WS_C * 4; asm volatile("" : "+s"(yb_c));
+      xb_c += WS_TM * WS_C * 4; asm volatile("" : "+s"(xb_c));
+      if constexpr (EP == 4) { gb_c += WS_TM * WS_C * 4; asm volatile("" : "+s"(gb_c)); }
+      stbase_p += WS_C * 8; asm volatile("" : "+s"(stbase_p));
+    } else {
+      xbase_d = row_ptr(a.x, Tnn.irow, WS_C * 4);
+      if constexpr (PRO2) x2base_d = row_ptr(a.nb_x, Tnn.irow, WS_C * 4);
+      aobase_t = const_cast<char*>(row_ptr(a.a_out, Tn.irow, WS_C * 2));
+      yb_c = block8(a.y, Tc);
+      xb_c = block8(a.ep_x, Tc);
+      if constexpr (EP == 4) gb_c = block8(a.ep_g2, Tc);
+      stbase_p = const_cast<char*>(row_ptr(a.stats, t - 1, WS_C * 8));     // tile t-1 of the launch
+    }
+    // (the strides hold from a fast iteration to the next fast one unless the tile after next was clamped)
+    ptr_step = fast && t + 3 < last;
     pl_cur = (it + 1) & 1 ? pl_off + WS_BUF_BYTES : pl_off;
     asm volatile("" : "+v"(pl_cur));
+    WSD_STAMP(it, 10);
+    if (cs_pending && !fast) colsum_out(t, it);
     if (doE && !fast) {                                     // pending section of the previous tile, not overlapped
       drain_vmem();
       asm volatile("s_nop 15\n\ts_nop 15" : "+v"(acc[1]));
-      epi_plain(std::integral_constant<int, 1>{}, Tp, yb_p, block8(a.ep_x, Tp.b, Tp.tile * WS_TM),
-                EP == 4 ? block8(a.ep_g2, Tp.b, Tp.tile * WS_TM) : nullptr);
+      epi_plain(std::integral_constant<int, 1>{}, Tp, yb_p, block8(a.ep_x, Tp), EP == 4 ? block8(a.ep_g2, Tp) : nullptr);
       epi_stats();
       pend_issued = false;
     }
     if (fast) {
       if (cur_eb != Tc.b) load_ep_consts(Tc.b);
       if (!pend_issued) {                                   // first overlapped tile behind a plain one
-        xcur = block8(a.ep_x, Tp.b, Tp.tile * WS_TM) + 2 * (16 * WS_C * 4);
-        if constexpr (EP == 4) gcur = block8(a.ep_g2, Tp.b, Tp.tile * WS_TM) + 2 * (16 * WS_C * 4);
+        xcur = block8(a.ep_x, Tp) + 2 * (16 * WS_C * 4);
+        if constexpr (EP == 4) gcur = block8(a.ep_g2, Tp) + 2 * (16 * WS_C * 4);
         ws_static_for<0, 16>([&](auto i_c) {
           epi_load(i_c, xcur, gcur);
           if constexpr (decltype(i_c)::value == 7) { WSD_STEP16(xcur); if constexpr (EP == 4) WSD_STEP16(gcur); }
@@ -621,12 +713,16 @@ __device__ __forceinline__ void wsd_body(const SaConvArgs& a, int tiles_per_wg, 
         drain_vmem();
       }
     }
+    WSD_STAMP(it, 0);
+    WSD_STAMP_RT(it, 5);
     // One tile: 2 x SECT single-MFMA asm statements with filler slot f behind statement f of a section.
     auto tile_body = [&](auto fast_c) {
       constexpr bool FAST = decltype(fast_c)::value;
       auto filler = [&](auto sec_c, auto f_c) {
         constexpr int sec = decltype(sec_c)::value, fs = decltype(f_c)::value;
         if constexpr (!FAST) return;
+        if constexpr (sec == 0 && fs == 0) { if (cs_pending) colsum_rd(it); }
+        if constexpr (sec == 0 && fs == 3) { if (cs_pending) colsum_wr(t); }
         constexpr int he = sec ^ 1;                         // the section whose accumulator the epilogue reads
         // running pointers of the three streams: set in the slot in front of a stream's first value,
         // advanced behind its eighth
@@ -636,7 +732,7 @@ __device__ __forceinline__ void wsd_body(const SaConvArgs& a, int tiles_per_wg, 
           else { WSD_STEP16(xcur); if constexpr (EP == 4) WSD_STEP16(gcur); }
         }
         // ---- epilogue stream: value v enters at slot E0 + v*EII, one level per slot ----
-        if constexpr (fs >= Sch::E0 && fs < Sch::EEND) {
+        if constexpr (fs >= Sch::E0 && fs < Sch::EEND && !(SA_WSD_ABL & 1)) {
           ws_static_for<0, 16>([&](auto v_c) {
             constexpr int v = decltype(v_c)::value, lv = fs - (Sch::E0 + v * Sch::EII);
             (void)&ssum; (void)&ssq; (void)&y_off;
@@ -645,6 +741,7 @@ __device__ __forceinline__ void wsd_body(const SaConvArgs& a, int tiles_per_wg, 
                 // the previous section issued this value's load(s) in its slot LB + v
                 // (the comment names the registers for tools/wsd_audit.py)
                 constexpr int N = Sch::nwait(sec ^ 1, v);
+                if constexpr (!(SA_WSD_ABL & (8 | 16)))
                 asm volatile("s_waitcnt vmcnt(%0) ; landed v%c1" :: "n"(N), "n"(WSD_XR0 + v) : "memory");
               }
               epi_level(std::integral_constant<int, he>{}, v_c, std::integral_constant<int, lv>{});
@@ -652,17 +749,19 @@ __device__ __forceinline__ void wsd_body(const SaConvArgs& a, int tiles_per_wg, 
           });
         }
         // ---- store burst: values 2k, 2k+1 in slot SB + k ----
-        if constexpr (fs >= Sch::SB && fs < Sch::SB + 8) {
+        if constexpr (fs >= Sch::SB && fs < Sch::SB + 8 && !(SA_WSD_ABL & (1 | 32))) {
           constexpr int k2 = 2 * (fs - Sch::SB);
           epi_store(std::integral_constant<int, k2>{}, ycur);
           epi_store(std::integral_constant<int, k2 + 1>{}, ycur);
           if constexpr (k2 == 6) WSD_STEP16(ycur);
         }
-        if constexpr (sec == 0 && fs == Sch::EEND) epi_stats();
+        if constexpr (sec == 0 && fs == Sch::EEND && !(SA_WSD_ABL & 1)) epi_stats();
+        if constexpr (sec == 1 && fs == 0) WSD_STAMP(it, 1);
+        if constexpr (fs == Sch::SB) WSD_STAMP(it, 6 + sec);
         // ---- transform stream ----
         constexpr int np = sec == 0 ? Sch::NP0 : Sch::NP1, jb = sec == 0 ? 0 : Sch::NP0;
-        if constexpr (fs == Sch::T0 - 3) piece_read(jb);
-        if constexpr (fs >= Sch::T0 && fs < Sch::T0 + np * Sch::SUBS) {
+        if constexpr (fs == Sch::T0 - 3 && !(SA_WSD_ABL & 2)) piece_read(jb);
+        if constexpr (fs >= Sch::T0 && fs < Sch::T0 + np * Sch::SUBS && !(SA_WSD_ABL & 2)) {
           constexpr int p = (fs - Sch::T0) / Sch::SUBS, k = (fs - Sch::T0) % Sch::SUBS, j = jb + p;
           if constexpr (PRO2) {
             if constexpr (k < 3) piece_level(Tn, j, k);
@@ -682,8 +781,10 @@ __device__ __forceinline__ void wsd_body(const SaConvArgs& a, int tiles_per_wg, 
           if constexpr (k == Sch::KD0) dma_piece(Tnn, false, j, 0);
           if constexpr (PRO2 && k == Sch::KD1) dma_piece(Tnn, false, j, 1);
         }
+        // column sums of the transformed tile: behind the last piece's sums, an LDS slot of section 1
+        if constexpr (PRO2 && sec == 1 && fs == Sch::T0 + Sch::NP1 * Sch::SUBS) colsum_put(it + 1);
         // ---- loads for the next section's epilogue: rows 32*sec .. of the current tile ----
-        if constexpr (fs >= Sch::LB && fs < Sch::LB + 16) {
+        if constexpr (fs >= Sch::LB && fs < Sch::LB + 16 && !(SA_WSD_ABL & (1 | 16))) {
           epi_load(std::integral_constant<int, fs - Sch::LB>{}, xcur, gcur);
           if constexpr (fs - Sch::LB == 7) { WSD_STEP16(xcur); if constexpr (EP == 4) WSD_STEP16(gcur); }
         }
@@ -697,10 +798,18 @@ __device__ __forceinline__ void wsd_body(const SaConvArgs& a, int tiles_per_wg, 
         constexpr int tp = s / WS_KSTEPS, k = s % WS_KSTEPS, sl = S & 1;
         constexpr bool more = S + 1 < 2 * Sch::NS;
         __builtin_amdgcn_sched_barrier(0);
+#if SA_WSD_ABL & 4
+#define WSD_MFMA(A, BC, B) asm volatile("" : "+v"(acc[sec]) : "v"(A), BC(B))
+#else
 #define WSD_MFMA(A, BC, B) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(acc[sec]) : "v"(A), BC(B))
+#endif
 #define WSD_SLOT(I) __builtin_amdgcn_sched_barrier(0); \
         filler(std::integral_constant<int, sec>{}, std::integral_constant<int, 3 * s + (I)>{}); __builtin_amdgcn_sched_barrier(0)
+#if SA_WSD_ABL & 4
+#define WSD_MFMA_LIT(A, R) asm volatile("" : "+v"(acc[sec]) : "v"(A))
+#else
 #define WSD_MFMA_LIT(A, R) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, a[" R "], %0" : "+v"(acc[sec]) : "v"(A))
+#endif
         constexpr bool hand = s >= WS_NAGPR_FRAGS && s < WS_NAGPR_FRAGS + WS_NHAND;
         if constexpr (s == 0) {
           asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, 0" : "=&v"(acc[sec]) : "v"(al), "a"(Bh[0][0]));
@@ -731,6 +840,7 @@ __device__ __forceinline__ void wsd_body(const SaConvArgs& a, int tiles_per_wg, 
     if (fast) {
       tile_body(std::true_type{});
       pend_issued = true;
+      WSD_STAMP(it, 2);
     } else {
       tile_body(std::false_type{});
       // MFMA result -> VALU reader wait states (the last MFMA of section 1 has just been issued; acc[0]
@@ -751,19 +861,20 @@ __device__ __forceinline__ void wsd_body(const SaConvArgs& a, int tiles_per_wg, 
       for (int j = 0; j < WS_DPW; ++j) dma_piece(Tnn, edgeD, j);
       pend_issued = false;
     }
-    colsum_put(it + 1);
+    if (!fast) colsum_put(it + 1);
+    WSD_STAMP(it, 3);
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();                          // planes[(it+1) & 1] complete; planes[it & 1] free
-    if (t + 1 < last) colsum_out(t + 1, it + 1);
+    WSD_STAMP(it, 4);
+    cs_pending = t + 1 < last;                            // column sums of tile t+1 wait in the LDS scratch
     Tp = Tc; Tc = Tn; Tn = Tnn;
   }
   // ================= tail: rows 32..63 of the last tile =================
   {
     drain_vmem();
     asm volatile("s_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15" : "+v"(acc[0]), "+v"(acc[1]));
-    stbase_p = const_cast<char*>(row_block(a.stats, Tp.b, a.ntiles, Tp.tile, WS_C * 8));
-    epi_plain(std::integral_constant<int, 1>{}, Tp, block8(a.y, Tp.b, Tp.tile * WS_TM), block8(a.ep_x, Tp.b, Tp.tile * WS_TM),
-              EP == 4 ? block8(a.ep_g2, Tp.b, Tp.tile * WS_TM) : nullptr);
+    stbase_p = const_cast<char*>(row_ptr(a.stats, last - 1, WS_C * 8));
+    epi_plain(std::integral_constant<int, 1>{}, Tp, block8(a.y, Tp), block8(a.ep_x, Tp), EP == 4 ? block8(a.ep_g2, Tp) : nullptr);
     epi_stats();
   }
 #undef WS_IDS
@@ -775,9 +886,12 @@ __device__ __forceinline__ void wsd_body(const SaConvArgs& a, int tiles_per_wg, 
 
 template <int NT, int HALO, int PRO, int EP>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) __attribute__((amdgpu_num_vgpr(240)))
-void sa_conv_wsd_kernel(SaConvArgs a, int tiles_per_wg, int total_tiles) {
-  wsd_body<NT, HALO, PRO, EP>(a, tiles_per_wg, total_tiles);
+void sa_conv_wsd_kernel(SaConvArgs a, int bcost, int total_tiles) {
+  wsd_body<NT, HALO, PRO, EP>(a, bcost, total_tiles);
 }
+
+// extra cost of an utterance end, in tiles (see wsd_body; tools/wsd_ablate.py --bcost sweeps it)
+int g_wsd_bcost = 5;
 
 template <int NT, int HALO, int PRO, int EP>
 int launch_wsd(const SaConvArgs& a, hipStream_t st) {
@@ -813,9 +927,8 @@ int launch_wsd(const SaConvArgs& a, hipStream_t st) {
     attr_set = true;
   }
   const int total = args.ntiles * a.B;
-  const int per = sa_div_up(total, n_cu);
-  const int nwg = sa_div_up(total, per);
-  hipLaunchKernelGGL(kern, dim3(nwg), dim3(256), lds, st, args, per, total);
+  const int nwg = total < n_cu ? total : n_cu;
+  hipLaunchKernelGGL(kern, dim3(nwg), dim3(256), lds, st, args, g_wsd_bcost, total);
   hipError_t e = hipGetLastError();
   return e == hipSuccess ? 0 : -(int)e;
 }
@@ -825,7 +938,7 @@ int wsd_variant(int dtype, int cin, int cout, int sa, int u, const SaConvArgs* a
   if (dtype != SA_BF16X3 || cin != 128 || cout != 128 || sa != 1 || u != 1) return 0;
   if (a->ep_mode != 1 && a->ep_mode != 2) return 0;
   if (!a->ep_x || !a->ep_mean || !a->ep_rstd || !a->stats) return 0;
-  if (a->s1 || a->t1 || a->s2 || a->t2 || a->swish || a->relu || a->pro_stats || a->wscale) return 0;
+  if (a->s1 || a->t1 || a->s2 || a->t2 || a->swish || a->relu || a->pro_stats || a->wscale || a->bias) return 0;
   if (a->tile_rows && a->tile_rows != 64) return 0;
   const int nt = a->taps.ntaps[0];
   if (nt != 5 && nt != 3) return 0;
@@ -852,6 +965,8 @@ int wsd_variant(int dtype, int cin, int cout, int sa, int u, const SaConvArgs* a
     if (a->ep_g2 || a->ep_bstride != 0) return 0;
     if (a->ep_xp_is_act) { if (!a->ep_s1 || !a->ep_t1) return 0; ep = 3; } else { if (a->ep_s1 || a->ep_t1) return 0; ep = 2; }
   }
+  // the ReLU mask of the prologue is compiled in: the BatchNorm blocks (EP 2, 3) have it, the InstanceNorm block not
+  if (pro == 2 && (a->nb_relu_mask != 0) != (ep != 1)) return 0;
   // the instantiations the train step needs
   if (nt == 5 && pro == 2 && ep == 1) return 1;            // encoder.11
   if (nt == 5 && pro == 2 && ep == 3) return 2;            // sex_classifier.tdnn.0
@@ -862,6 +977,12 @@ int wsd_variant(int dtype, int cin, int cout, int sa, int u, const SaConvArgs* a
 }
 
 }  // namespace
+
+extern "C" int sa_conv_wsd_set_bcost(int tiles) {
+  if (tiles < 0 || tiles > 64) return -22;
+  g_wsd_bcost = tiles;
+  return 0;
+}
 
 // Does the fused data-gradient kernel serve this launch?  (sa_conv_gemm.hip asks before routing.)
 bool sa_conv_wsd_covers(int dtype, int cin, int cout, int sa, int u, const SaConvArgs* a) {

@@ -241,7 +241,10 @@ def conv_gemm(x, wp, bias, cin, cout, sa, u, phases, Lout, s1=None, t1=None, s2=
         route = lib.sa_conv_gemm_route(kc, cin, cout, sa, u, C.byref(a))
         tname = {L.F32: "float", L.BF16: "bf16_t", L.BF16X3: "bf16x3_t", L.BF16X1F: "bf16x1f_t", L.FP8: "fp8_t"}[kc]
         ws_mode = (5 if s2 is not None else 0) if s1 is None else 3 if want_pro_stats else 4 if s2 is not None else 1
-        kind = (f"sa_conv_ws_kernel<{ws_mode},{ntap}> ({tname}, {cin}->{cout})" if route == 2 else
+        offs = [o for ph in phases for o, _ in ph]
+        wsd_ep = 0 if not ep else (4 if ep.get("g2") is not None else 1) if int(ep["mode"]) == 1 else (3 if ep.get("xp_is_act") else 2)
+        kind = (f"sa_conv_wsd_kernel<{ntap},{max(offs) - min(offs)},{2 if nb else 0},{wsd_ep}> ({tname}, {cin}->{cout})" if route == 3 else
+                f"sa_conv_ws_kernel<{ws_mode},{ntap}> ({tname}, {cin}->{cout})" if route == 2 else
                 f"sa_conv_pp_kernel<{tname},{cin},{cout},{sa},{u}>" if route == 1 else
                 f"sa_conv_gemm_kernel<{tname},{cin},{cout},{sa},{u}{',nb prologue' if nb else ''}>")
         PROFILE.stop(e0, io + ntap * cin * cout * esz + extra,
@@ -591,6 +594,20 @@ def cosine_loss(x1, x2, want_grad=False):
     L.check(lib.sa_cosine_loss(_f(x1), _f(x2), B, S, D, _f(rl), _f(loss), _f(dx1), L.stream()),
             "sa_cosine_loss")
     return loss, dx1
+
+
+def cosine_rows(x1, x2):
+    """per-row cosine similarity of two [B, D] tensors (sa_cosine_loss's row output: 1 - loss of
+    the row; eps 1e-6 on |x1||x2|, where torch.nn.CosineSimilarity(eps=1e-8) of the reference's
+    evaluation hook differs only for vectors of norm < 1e-3)."""
+    lib = L.load()
+    B, D = x1.shape
+    x1, x2 = x1.contiguous().float(), x2.contiguous().float()
+    rl = torch.empty(B, dtype=torch.float32, device=x1.device)
+    loss = torch.empty(1, dtype=torch.float32, device=x1.device)
+    L.check(lib.sa_cosine_loss(_f(x1), _f(x2), B, 1, D, _f(rl), _f(loss), None, L.stream()),
+            "sa_cosine_loss")
+    return 1.0 - rl
 
 
 def cluster_mi(X, y, idx=None, ncls=2, k=3):

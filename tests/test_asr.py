@@ -142,3 +142,42 @@ def test_brain_adds_the_utility_term():
     g = brain.modules.ConvAE.decoder[8].weight.grad if hasattr(brain.modules.ConvAE, "decoder") else None
     assert g is None or torch.isfinite(g).all()
     assert any(p.grad is not None and float(p.grad.abs().sum()) > 0 for p in brain.modules.ConvAE.parameters())
+
+
+@pytest.mark.gpu
+def test_utility_retention_reaches_the_valid_stats():
+    """speechbrain_convae_train.py:156-163 + :338-343: at VALID with a recogniser attached, every
+    batch appends the per-utterance cosine similarity of the recogniser's encoder outputs on the
+    reconstructed and on the original features (the library's sa_cosine_loss row output);
+    on_stage_end reports their mean as Utility_Retention."""
+    import bench
+    from speech_anonymization_amd.brain import Stage
+    dev = torch.device("cuda", 0)
+    brain = bench.build_brain(dev, "bf16x3", 3)
+    brain.asr_brain = _small(torch.bfloat16).to(dev)
+    brain.modules.ConvAE.pooling_noise = None
+    brain.hparams.epoch_counter.current = 10
+    brain.modules.eval()
+    brain.on_stage_start(Stage.VALID, 1)
+    want = []
+    for seed in (0, 1):
+        batch = bench.synthetic_batch(3, seed, dev, n_samples=36 * 160 * 2 - 160)
+        tok = torch.randint(3, 50, (3, 5), device=dev)
+        tok[:, 0] = 1
+        batch.tokens_bos = (tok, torch.ones(3, device=dev))
+        brain.evaluate_batch(batch, Stage.VALID)
+        with torch.no_grad():
+            feats = brain.features(*batch.sig)
+            recon, _ = brain.modules.ConvAE(feats)
+            e_r, _ = brain.asr_brain.get_predictions(recon, batch.sig[1], tok, eval=True)
+            e_o, _ = brain.asr_brain.get_predictions(feats, batch.sig[1], tok, eval=True)
+            want.append(torch.nn.functional.cosine_similarity(e_r.reshape(3, -1).float(), e_o.reshape(3, -1).float(),
+                                                              dim=-1, eps=1e-8))
+    want = torch.cat(want)
+    got = torch.stack(list(brain.utility_similarity_aggregator.scores)) if isinstance(
+        brain.utility_similarity_aggregator.scores, list) else brain.utility_similarity_aggregator.scores
+    assert got.shape == want.shape and torch.allclose(got, want, atol=2e-5), (got, want)
+    brain.train_stats = {"loss": 0.0}
+    brain.on_stage_end(Stage.VALID, 0.5, 1)
+    assert abs(brain.valid_stats["Utility_Retention"] - float(want.mean())) < 2e-5
+    assert 0.0 < brain.valid_stats["Utility_Retention"] < 1.0

@@ -958,6 +958,101 @@ def test_weight_stationary_conv_kernel_random_lengths():
         ops.conv_impl()
 
 
+WSD_CASES = [
+    # name, K, dil, pad, Lin, prologue (None | "in" | "bn"), epilogue variant, second gradient
+    ("enc11", 5, 1, 2, 20160, "in", 1, False),      # InstanceNorm prologue, (acc) * swish'(z)
+    ("tdnn0", 5, 1, 0, 20156, "bn", 3, False),      # BatchNorm + ReLU-mask prologue, xhat from swish(z)
+    ("dec0", 5, 1, 2, 20160, None, 1, True),        # plain rows, pending BatchNorm apply as addend
+    ("tdnn3", 3, 2, 0, 20152, "bn", 2, False),      # 3 taps dilation 2, partial last tile
+    ("tdnn6", 3, 3, 0, 20146, "bn", 2, False),      # 3 taps dilation 3
+    ("enc11_ragged", 5, 1, 2, 20001, "in", 1, False),
+    ("tdnn3_short", 3, 2, 0, 5003, "bn", 2, False), # many utterances: tile ranges cross utterance ends
+]
+
+
+@pytest.mark.parametrize("case", WSD_CASES, ids=[c[0] for c in WSD_CASES])
+def test_weight_stationary_fused_data_gradient_kernel(case):
+    """sa_conv_wsd.hip (persistent, weights in registers, rows by LDS-DMA, prologue / epilogue in the
+    MFMA loop's issue gaps, values loaded across the loop's back edge in reserved registers) serves
+    the five 128 -> 128 fused data gradients of a step: same y and bf16 d y BITS as the one-tile
+    kernel (sa_conv_gemm_kernel<bf16x3_t,128,128,1,1,64,PRO2>: same operand split, accumulation order
+    and epilogue operations), column sums bit-equal, statistics equal up to the order of the in-tile
+    sums; run twice: a stale in-flight load would show as a run-to-run difference."""
+    import ctypes as C
+    from speech_anonymization_amd import _lib as L, ops
+    name, K, dil, pad, Lin, nbk, epk, g2 = case
+    d = dev()
+    B = 24 if "short" in name else 6
+    g = torch.Generator().manual_seed(3)
+    Lout = Lin + dil * (K - 1) - 2 * pad
+    x = torch.randn(B, Lin, 128, generator=g).to(d)
+    w = (torch.randn(128, 128, K, generator=g) * 0.05).to(d)
+    wd = ops.pack_weights(w, "conv_dgrad", torch.float32, L.BF16X3)
+    taps = ops.taps_conv_dgrad_s1(K, dil, pad)
+    kw = dict(code=L.BF16X3, want_stats=True)
+    if nbk:
+        per_c = nbk == "bn"
+        shp = (128,) if per_c else (B, 128)
+        c = [(torch.rand(*shp, generator=g) + 0.5).to(d), (torch.randn(*shp, generator=g) * 0.1).to(d),
+             (torch.randn(*shp, generator=g) * 0.05).to(d)]
+        y2 = torch.randn(B, Lin, 128, generator=g).to(d)
+        kw["nb"] = dict(x=y2, c1=c[0], c2=c[1], c3=c[2], per_c=per_c, relu_mask=per_c, want_colsum=True)
+    xe = torch.randn(B, Lout, 128, generator=g).to(d)
+    s1 = (torch.rand(B, 128, generator=g) + 0.5).to(d)
+    t1 = (torch.randn(B, 128, generator=g) * 0.1).to(d)
+    if epk == 1:
+        mean, rstd = (torch.randn(B, 128, generator=g) * 0.1).to(d), (torch.rand(B, 128, generator=g) + 0.5).to(d)
+        kw["ep"] = dict(mode=1, x=xe, s1=s1, t1=t1, mean=mean, rstd=rstd)
+        if g2:
+            kw["ep"]["g2"] = torch.randn(B, Lout, 128, generator=g).to(d)
+            kw["ep"]["g2k"] = [(torch.rand(128, generator=g) + 0.5).to(d), (torch.randn(128, generator=g) * 0.1).to(d),
+                               (torch.randn(128, generator=g) * 0.05).to(d)]
+    else:
+        mean, rstd = (torch.randn(128, generator=g) * 0.1).to(d), (torch.rand(128, generator=g) + 0.5).to(d)
+        kw["ep"] = dict(mode=2, x=xe, mean=mean, rstd=rstd, per_c=True)
+        if epk == 3:
+            kw["ep"].update(s1=s1, t1=t1, xp_is_act=True)
+
+    def run(ws):
+        ops.conv_impl(ws=ws)
+        ao = torch.full((B, Lin, 128), float("nan"), device=d, dtype=torch.bfloat16) if nbk else None
+        out = ops.conv_gemm(x, wd, None, 128, 128, 1, 1, taps, Lout, a_out=ao, **kw)
+        torch.cuda.synchronize()
+        return tuple(out) + ((ao,) if ao is not None else ())
+
+    try:
+        ref, got, again = run(False), run(True), run(True)
+        a = L.SaConvArgs()
+        a.B, a.Lin, a.Lout = B, Lin, Lout
+        a.taps = L.make_taps(taps)
+        a.stats, a.ep_x, a.ep_mean, a.ep_rstd = ops._f(ref[1]), ops._f(xe), ops._f(mean), ops._f(rstd)
+        a.ep_mode, a.ep_bstride, a.ep_xp_is_act = (1 if epk == 1 else 2), (128 if epk == 1 else 0), int(epk == 3)
+        if epk in (1, 3):
+            a.ep_s1, a.ep_t1 = ops._f(s1), ops._f(t1)
+        if g2:
+            a.ep_g2 = ops._f(kw["ep"]["g2"])
+            a.ep_g2k1, a.ep_g2k2, a.ep_g2k3 = (ops._f(t) for t in kw["ep"]["g2k"])
+        if nbk:
+            a.nb_x, a.nb_c1, a.nb_c2, a.nb_c3 = ops._f(y2), ops._f(c[0]), ops._f(c[1]), ops._f(c[2])
+        assert L.load().sa_conv_gemm_route(L.BF16X3, 128, 128, 1, 1, C.byref(a)) == 3
+    finally:
+        ops.conv_impl()
+    assert torch.equal(ref[0], got[0]) and torch.equal(got[0], again[0])                 # y
+    assert torch.allclose(ref[1], got[1], rtol=2e-5, atol=2e-3) and torch.equal(got[1], again[1])   # statistics slabs
+    if nbk:
+        assert torch.equal(ref[2], got[2])                                               # column sums of d y
+        assert not torch.isnan(got[3].float()).any() and torch.equal(ref[3], got[3])     # bf16 d y
+    # anchor: the one-tile kernel against fp32 torch (plain rows, mode 1: dx = conv_transpose(dy) * swish'(z) ...)
+    if name == "dec0":
+        dyr = F.conv_transpose1d(x.permute(0, 2, 1), w, padding=pad).permute(0, 2, 1)
+        z = xe * s1[:, None, :] + t1[:, None, :]
+        sg = torch.sigmoid(z)
+        k1, k2, k3 = kw["ep"]["g2k"]
+        g2v = k1 * kw["ep"]["g2"] + k2 * (z * sg) + k3
+        want = (dyr + g2v) * (sg * (1 + z * (1 - sg)))
+        assert rel_mse(got[0], want) < 2e-9
+
+
 def test_weight_stationary_conv_routing():
     """what goes to the weight-stationary kernel: bf16x3 128->128 stride-1 5-tap launches with at
     least 1536 tiles (six per CU) and no fused backward epilogue / normalisation-backward prologue;

@@ -86,6 +86,45 @@ def test_hip_graph_step_equals_eager_steps():
             assert float((p0[k] - p1[k]).abs().max()) <= 2e-6 + 1e-5 * float(p0[k].abs().max()), k
 
 
+def test_hip_graph_follows_the_epoch_parity_schedule():
+    """hipGraph mode over epochs 0, 1, 2 of HEAD's epoch-parity schedule
+    (speechbrain_convae_train.py:212-235).  Epoch 0 freezes the classifier while it has no Adam
+    moments (it stays out of the update); epoch 1 trains it; in epoch 2 it is frozen again but now
+    HAS moments, and torch 1.10's zero-filled gradients keep moving it -- the same requires_grad
+    pattern as epoch 0 with a different step.  The graph key carries the optimizer state of the
+    frozen parameters, so epoch 2 captures its own graph; parameters equal the eager run's."""
+    from oracle.convae import numpy_params
+    from tests import smoke_step
+    from speech_anonymization_amd.brain import Batch
+    dev = torch.device("cuda:0")
+    wav = smoke_step.make_wave(4, 11360)
+    scales = (1.0, 0.9, 0.8, 1.1, 0.7)
+    runs = []
+    for graph in (False, True):
+        br = smoke_step.build("bf16x3", dev, numpy_params(8886))
+        br.hparams.epoch_parity_schedule = True
+        if graph:
+            br.hip_graph, br.optimizer = True, None
+            br.init_optimizers()
+        for epoch in (0, 1, 2):
+            br.hparams.epoch_counter.current = epoch
+            for s_ in scales:
+                br.step += 1
+                br.fit_batch(Batch(wav * s_, torch.tensor([1.0, 0.83, 0.61, 1.0]), torch.arange(4) % 2))
+        torch.cuda.synchronize()
+        if graph:
+            assert len(br._graphs) == 3, list(br._graphs)          # one per epoch: 0 and 2 differ by the moments
+        runs.append({k: v.detach().clone() for k, v in br.modules["ConvAE"].state_dict().items()})
+    p0, p1 = runs
+    moved = 0
+    for k in p0:
+        if p0[k].dtype.is_floating_point:
+            assert float((p0[k] - p1[k]).abs().max()) <= 5e-6 + 2e-5 * float(p0[k].abs().max()), k
+    # the classifier did move in epoch 2 of the eager run (the semantics under test)
+    ref = numpy_params(8886)
+    assert float((p0["sex_classifier.classify.6.weight"].cpu() - ref["sex_classifier.classify.6.weight"]).abs().max()) > 0
+
+
 def test_frozen_classifier_and_recon_only():
     """the reference's requires_grad toggling by name (speechbrain_convae_train.py:219-235) and
     config 1 (recon 1.0 only, MSE): frozen parameters get no gradient, the rest still match."""

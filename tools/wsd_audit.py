@@ -2,8 +2,9 @@
 waits of the tile body are inline asm, so hipcc neither knows their latency nor counts them):
   1. no scratch access between the first and the last MFMA of a kernel (a lane constant parked in
      scratch at kernel entry and fetched back in the tail is tolerated and reported);
-  2. every section of a tile body accumulates into ONE register block, the two sections into two
-     different blocks, the same two in every body;
+  2. every section of a tile body accumulates into ONE register block, the two sections of a body into
+     two different blocks (the overlapped and the plain copy of the body may use different pairs: the
+     compiler then moves a live accumulator between them at the loop top, behind the tile barrier);
   3. while a section accumulates (from its C = 0 MFMA to its last MFMA) no compiler-generated
      instruction touches its block, and none READS it sooner than three MFMA statements after the
      last MFMA that wrote it (outside that window the block is an ordinary value: once its epilogue
@@ -11,7 +12,8 @@ waits of the tile body are inline asm, so hipcc neither knows their latency nor 
   4. the reserved registers v240..v255 / a240..a255 (values loaded across the tile loop's back edge,
      hand-placed weights) appear in no compiler-generated instruction, and the kernel descriptor
      covers them (accum_offset 256, 256 accumulator registers);
-  5. no compiler-inserted s_waitcnt vmcnt inside the overlapped body.
+  5. no compiler-inserted s_waitcnt vmcnt inside the overlapped body;
+  6. no compiler-generated instruction reads or writes m0 (the LDS-DMA statements set it and leave it).
   python tools/wsd_audit.py        (exit 1 on a finding; compiles only, runs on the CPU box)"""
 import os, re, subprocess, sys, tempfile
 R = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -60,15 +62,18 @@ for k in kernels:
     for i in range(idx[0], idx[-1] + 1):
         if lines[i].strip().startswith("scratch_"):
             finding(f"scratch access inside the tile loop: {lines[i].strip()}")
-    if len(set(blk)) != 2 or nsec % 2 or any(starts[n] != n * sect for n in range(nsec)):
-        finding("accumulators migrate / irregular sections")
+    if nsec % 2 or any(starts[n] != n * sect for n in range(nsec)):
+        finding("irregular sections")
         continue
     for n in range(nsec):
-        if len(set(blk[starts[n]:starts[n] + sect])) != 1 or blk[starts[n]] != blk[starts[n % 2]]:
-            finding(f"section {n}: more than one block, or not the block of section {n % 2}")
-    accregs = [regs_of(blk[0]), regs_of(blk[sect])]
+        if len(set(blk[starts[n]:starts[n] + sect])) != 1:
+            finding(f"section {n}: more than one accumulator block")
+    for body in range(nsec // 2):
+        if blk[starts[2 * body]] == blk[starts[2 * body + 1]]:
+            finding(f"body {body}: both sections on one block")
     # walk every body (two sections): classify lines as asm / compiler
     for body in range(nsec // 2):
+        accregs = [regs_of(blk[starts[2 * body]]), regs_of(blk[starts[2 * body + 1]])]
         first, last = idx[starts[2 * body]], idx[starts[2 * body] + 2 * sect - 1]
         in_asm, since = True, [10 ** 6, 10 ** 6]          # MFMA statements since the last write of block 0 / 1
         left = [0, 0]                                        # MFMAs the block's running section still has to issue
@@ -114,6 +119,8 @@ for k in kernels:
         elif not in_asm and l.startswith("\t") and not l.strip().startswith((";", ".")):
             ops = l.strip().split(None, 1)
             if len(ops) > 1:
+                if re.search(r"\bm0\b", ops[1]):
+                    finding(f"compiler instruction uses m0 (the LDS-DMA statements do not preserve it): {l.strip()}")
                 if regs_of(ops[1]) & set(range(240, 256)):
                     finding(f"compiler instruction names a reserved vector register: {l.strip()}")
                 for m in re.finditer(r"\ba\[(\d+):(\d+)\]|\ba(\d+)\b", ops[1]):
