@@ -147,4 +147,32 @@ class Checkpointer:
                 obj.current = int(open(fn).read().strip())
             else:
                 obj.load_state_dict(torch.load(fn, map_location=device or "cpu", weights_only=True))
+        if brain is not None and "optimizer" in self.recoverables:
+            self._rebind_optimizer(brain)
         return path
+
+    @staticmethod
+    def _rebind_optimizer(brain):
+        """optimizer.load_state_dict replaces the param_groups wholesale: a checkpoint written by an
+        eager run carries lr as a Python float and capturable=False, one written in hipGraph mode a
+        device tensor and capturable=True.  Put the groups back into the form THIS run's mode needs
+        (and Noam's host copy of the rate), whichever mode wrote the checkpoint."""
+        opt = brain.optimizer
+        if opt is None:
+            return
+        for g in opt.param_groups:
+            lr = float(g["lr"])
+            opt._sa_host_lr = lr
+            if getattr(brain, "hip_graph", False):
+                g["lr"] = torch.tensor(lr, dtype=torch.float32, device=brain.device)
+                if "capturable" in g:
+                    g["capturable"] = True
+            else:
+                g["lr"] = lr
+                if "capturable" in g:
+                    g["capturable"] = False
+        for p_, st in opt.state.items():                   # Adam's step counters follow the mode too
+            if "step" in st and torch.is_tensor(st["step"]):
+                want = brain.device if getattr(brain, "hip_graph", False) else torch.device("cpu")
+                if st["step"].device != want:
+                    st["step"] = st["step"].to(want)

@@ -90,7 +90,7 @@ namespace {
 // 5: one per-channel affine only (the dilated TDNN layers: BatchNorm of the layer below in front)
 template <int MODE, int NT, int HALO, int CC = 128, int CO = CC, int SA = 1, int UU = 1>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1)))
-void sa_conv_ws_kernel(SaConvArgs a, int tiles_per_wg, int total_tiles) {
+void sa_conv_ws_kernel(SaConvArgs a, int bcost, int total_tiles) {
   typedef WsGeo<CC, NT, HALO, CO, SA, UU> G;
   constexpr int WS_CO = G::CO, WS_SA = G::SA, WS_BM = G::BM;
   static_assert(UU == 1 || MODE == 0, "transposed layers: plain rows");
@@ -116,9 +116,22 @@ void sa_conv_ws_kernel(SaConvArgs a, int tiles_per_wg, int total_tiles) {
   const int wn_ = wave_ % NWN, wm_ = wave_ / NWN;           // this wave's column block / row half (or phase) of the tile
   const int ph_ = UU == 2 ? wm_ % 2 : 0, rh_ = UU == 2 ? wm_ / 2 : wm_;   // output phase, row half
   const int ntap_ = a.taps.ntaps[ph_];                      // (transposed layers: 3 and 2)
-  const int first = blockIdx.x * tiles_per_wg;
-  int last = first + tiles_per_wg;
-  if (last > total_tiles) last = total_tiles;
+  // This workgroup's contiguous tile range, cut at equal COST: the few tiles around the end of an
+  // utterance run un-overlapped (about `bcost` tiles' worth of extra time per utterance end; measured
+  // with tools/wsd_stamps.py on the data-gradient kernel, which shares this structure), and a launch
+  // ends with its slowest workgroup.  An utterance counts ntiles + bcost.
+  int first, last;
+  {
+    const unsigned long long U = (unsigned long long)a.ntiles + (unsigned)bcost;
+    const unsigned long long ctot = (unsigned long long)(total_tiles / a.ntiles) * U;
+    auto inv = [&](unsigned long long c) {                  // first tile whose cumulative cost reaches c
+      const unsigned long long k = c / U, r = c - k * U;
+      const unsigned long long t = k * (unsigned)a.ntiles + (r < (unsigned)a.ntiles ? r : (unsigned)a.ntiles);
+      return (int)(t < (unsigned)total_tiles ? t : (unsigned)total_tiles);
+    };
+    first = inv(ctot * blockIdx.x / gridDim.x);
+    last = blockIdx.x + 1 == gridDim.x ? total_tiles : inv(ctot * (blockIdx.x + 1) / gridDim.x);
+  }
   if (first >= last) return;
 
   // ---- the weights: this wave's 32 output columns, all taps / channels, hi and lo images ----
@@ -174,14 +187,36 @@ void sa_conv_ws_kernel(SaConvArgs a, int tiles_per_wg, int total_tiles) {
 #define WS_IDS int lane = lane_, wave = wave_; asm volatile("" : "+v"(lane), "+s"(wave)); (void)wave; (void)lane
 
   // tile index -> (utterance, tile of the utterance) and what the slots need of it
-  struct Tile { int b, tile; };
-  auto tile_of = [&](int t) { Tile r; r.b = t / a.ntiles; r.tile = t - r.b * a.ntiles; return r; };
-  auto next_tile = [&](Tile T) { Tile r; const bool wrap = T.tile + 1 == a.ntiles; r.b = wrap ? T.b + 1 : T.b; r.tile = wrap ? 0 : T.tile + 1; return r; };
-  // rows outside the utterance among the 68 staged ones, or the trailing rows it owns beyond its 64
-  auto is_edge = [&](Tile T) {
-    const int g0 = T.tile * (WS_BM * WS_SA) + a.rowmin;
-    return g0 < 0 || g0 + WS_ROWS > a.Lin || T.tile == a.ntiles - 1;
+  // a tile = (utterance, tile of the utterance) + its first staged input row, first output row and first
+  // statistics slab in the [B*Lin] / [B*Lout] / [B*slabs] index spaces, advanced incrementally (the
+  // per-tile bookkeeping is scalar code between two tile bodies: nothing overlaps it)
+  struct Tile { int b, tile, irow, orow, srow; };
+  // (two slabs per tile: the caller's slab count per utterance is that of 64-base-row tiles, possibly odd)
+  const int slab_short = G::SLABS == 2 ? 2 * a.ntiles - (((a.Lout + UU - 1) / UU + 63) / 64) : 0;
+  const int nslab_b = a.ntiles * G::SLABS - slab_short;
+  auto tile_of = [&](int t) {
+    Tile r; r.b = t / a.ntiles; r.tile = t - r.b * a.ntiles;
+    r.irow = r.b * a.Lin + r.tile * (WS_BM * WS_SA) + a.rowmin; r.orow = r.b * a.Lout + r.tile * WS_TM;
+    r.srow = r.b * nslab_b + r.tile * G::SLABS;
+    return r;
   };
+  const int iwrap = a.Lin - (a.ntiles - 1) * (WS_BM * WS_SA), owrap = a.Lout - (a.ntiles - 1) * WS_TM,
+            swrap = nslab_b - (a.ntiles - 1) * G::SLABS;
+  auto next_tile = [&](Tile T) {
+    Tile r; const bool wrap = T.tile + 1 == a.ntiles;
+    r.b = wrap ? T.b + 1 : T.b; r.tile = wrap ? 0 : T.tile + 1;
+    r.irow = T.irow + (wrap ? iwrap : WS_BM * WS_SA); r.orow = T.orow + (wrap ? owrap : WS_TM);
+    r.srow = T.srow + (wrap ? swrap : G::SLABS);
+    return r;
+  };
+  // rows outside the utterance among the 68 staged ones, or the trailing rows it owns beyond its 64
+  // tile*BM*SA + rowmin < 0, tile*BM*SA + rowmin + ROWS > Lin, or the last tile: two thresholds on the tile index
+  auto floor_div = [](int n, int d) { return n >= 0 ? n / d : -((-n + d - 1) / d); };
+  const int edge_lo = a.rowmin < 0 ? (-a.rowmin + WS_BM * WS_SA - 1) / (WS_BM * WS_SA) : 0;
+  int edge_hi = floor_div(a.Lin - WS_ROWS - a.rowmin, WS_BM * WS_SA);
+  if (edge_hi > a.ntiles - 2) edge_hi = a.ntiles - 2;
+  const int part_hi = floor_div(a.Lout - WS_TM, WS_TM);     // tiles beyond it are partial output tiles
+  auto is_edge = [&](Tile T) { return T.tile < edge_lo || T.tile > edge_hi; };
 
   // per-utterance transform constants (reloaded when the tile range crosses an utterance)
   float s1[4], t1[4], k1[4], k2[4], k3[4], s2[4], t2[4];
@@ -222,6 +257,11 @@ void sa_conv_ws_kernel(SaConvArgs a, int tiles_per_wg, int total_tiles) {
   const char* xbase_d = nullptr; const char* x2base_d = nullptr;    // rows of the DMA tile (x, nb_x)
   char* aobase_t = nullptr;                                          // a_out rows of the transform tile
   char* ybase_e = nullptr;                                           // y rows of the epilogue tile
+  auto row_ptr = [&](const void* p, int row, int row_bytes) {
+    const char* r = reinterpret_cast<const char*>(p) + (long)row * row_bytes;   // B*L rows < 2^31 (checked at launch)
+    asm volatile("" : "+s"(r));
+    return r;
+  };
   auto row_block = [&](const void* p, int b, int L, int row, int row_bytes) {
     const char* r = reinterpret_cast<const char*>(p) + (long)(b * L + row) * row_bytes;   // B*L rows < 2^31 (checked at launch)
     asm volatile("" : "+s"(r));
@@ -458,8 +498,6 @@ void sa_conv_ws_kernel(SaConvArgs a, int tiles_per_wg, int total_tiles) {
   bool st_pending = false;                                  // (64 channels) partial sums wait in LDS for the tile barrier
   int st_it = 0;
   char* stbase_e = nullptr;                                 // statistics slab of the epilogue tile
-  // (two slabs per tile: the caller's slab count per utterance is that of 64-base-row tiles, possibly odd)
-  const int slab_short = G::SLABS == 2 ? 2 * a.ntiles - (((a.Lout + UU - 1) / UU + 63) / 64) : 0;
   auto epi_stats = [&](Tile T, int part = 2) {              // 0: fold the lane halves, 1: store, 2: both
     if (has_stats) {
       if (part != 1) {
@@ -506,14 +544,14 @@ void sa_conv_ws_kernel(SaConvArgs a, int tiles_per_wg, int total_tiles) {
   for (int q = 0; q < 4; ++q) { csum[q] = 0.0f; csq[q] = 0.0f; }
   {
     const bool ec = is_edge(Tc), en = is_edge(Tn);
-    xbase_d = row_block(a.x, Tc.b, a.Lin, Tc.tile * (WS_BM * WS_SA) + a.rowmin, WS_C * 4);
-    if constexpr (PRO2) x2base_d = row_block(a.nb_x, Tc.b, a.Lin, Tc.tile * (WS_BM * WS_SA) + a.rowmin, WS_C * 4);
-    aobase_t = const_cast<char*>(row_block(a.a_out, Tc.b, a.Lin, Tc.tile * (WS_BM * WS_SA) + a.rowmin, WS_C * 2));
+    xbase_d = row_ptr(a.x, Tc.irow, WS_C * 4);
+    if constexpr (PRO2) x2base_d = row_ptr(a.nb_x, Tc.irow, WS_C * 4);
+    aobase_t = const_cast<char*>(row_ptr(a.a_out, Tc.irow, WS_C * 2));
     pl_cur = pl_off;
 #pragma unroll
     for (int j = 0; j < WS_DPW; ++j) dma_piece(Tc, ec, j);
-    xbase_d = row_block(a.x, Tn.b, a.Lin, Tn.tile * (WS_BM * WS_SA) + a.rowmin, WS_C * 4);
-    if constexpr (PRO2) x2base_d = row_block(a.nb_x, Tn.b, a.Lin, Tn.tile * (WS_BM * WS_SA) + a.rowmin, WS_C * 4);
+    xbase_d = row_ptr(a.x, Tn.irow, WS_C * 4);
+    if constexpr (PRO2) x2base_d = row_ptr(a.nb_x, Tn.irow, WS_C * 4);
     if (SWISH || PRO2) load_consts(Tc.b);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #pragma unroll
@@ -557,17 +595,17 @@ void sa_conv_ws_kernel(SaConvArgs a, int tiles_per_wg, int total_tiles) {
     const bool doE = t > first, doT = t + 1 < last;
     const Tile Tnn = t + 2 < last ? next_tile(Tn) : Tn;       // (clamped: Tn is already the last tile then)
     const bool edgeT = is_edge(Tn), edgeD = is_edge(Tnn);
-    const bool partialE = Tp.tile * WS_TM + WS_TM > a.Lout;
+    const bool partialE = Tp.tile > part_hi;
     // the slots hold the interior forms only; a tile at the end of an utterance (2 of 315 at the
     // training length) gets its masked transform / clamped DMA after the loop, a partial output tile
     // its bounds-checked epilogue in front of it, not overlapped
     const bool slotE = doE && !partialE, slotT = !edgeT, slotD = !edgeT && !edgeD;
     if ((SWISH || PRO2) && Tn.b != cur_b) load_consts(Tn.b);
-    xbase_d = row_block(a.x, Tnn.b, a.Lin, Tnn.tile * (WS_BM * WS_SA) + a.rowmin, WS_C * 4);
-    if constexpr (PRO2) x2base_d = row_block(a.nb_x, Tnn.b, a.Lin, Tnn.tile * (WS_BM * WS_SA) + a.rowmin, WS_C * 4);
-    aobase_t = const_cast<char*>(row_block(a.a_out, Tn.b, a.Lin, Tn.tile * (WS_BM * WS_SA) + a.rowmin, WS_C * 2));
-    ybase_e = const_cast<char*>(row_block(a.y, Tp.b, a.Lout, Tp.tile * WS_TM, WS_CO * 4));
-    stbase_e = const_cast<char*>(row_block(a.stats, Tp.b, a.ntiles * G::SLABS - slab_short, Tp.tile * G::SLABS, WS_CO * 8));
+    xbase_d = row_ptr(a.x, Tnn.irow, WS_C * 4);
+    if constexpr (PRO2) x2base_d = row_ptr(a.nb_x, Tnn.irow, WS_C * 4);
+    aobase_t = const_cast<char*>(row_ptr(a.a_out, Tn.irow, WS_C * 2));
+    ybase_e = const_cast<char*>(row_ptr(a.y, Tp.orow, WS_CO * 4));
+    stbase_e = const_cast<char*>(row_ptr(a.stats, Tp.srow, WS_CO * 8));
     st_slab_ok = G::SLABS == 1 || Tp.tile * 2 + rh_ < a.ntiles * 2 - slab_short;
     pl_cur = (it + 1) & 1 ? pl_off + WS_BUF_BYTES : pl_off;
     asm volatile("" : "+v"(pl_cur));
@@ -751,9 +789,9 @@ void sa_conv_ws_kernel(SaConvArgs a, int tiles_per_wg, int total_tiles) {
   }
   // ================= tail: epilogue of the last tile =================
   {
-    const bool partialE = Tp.tile * WS_TM + WS_TM > a.Lout;
-    ybase_e = const_cast<char*>(row_block(a.y, Tp.b, a.Lout, Tp.tile * WS_TM, WS_CO * 4));
-    stbase_e = const_cast<char*>(row_block(a.stats, Tp.b, a.ntiles * G::SLABS - slab_short, Tp.tile * G::SLABS, WS_CO * 8));
+    const bool partialE = Tp.tile > part_hi;
+    ybase_e = const_cast<char*>(row_ptr(a.y, Tp.orow, WS_CO * 4));
+    stbase_e = const_cast<char*>(row_ptr(a.stats, Tp.srow, WS_CO * 8));
     st_slab_ok = G::SLABS == 1 || Tp.tile * 2 + rh_ < a.ntiles * 2 - slab_short;
     if (!partialE) eval = epi_form(0);
 #pragma unroll
@@ -767,6 +805,9 @@ void sa_conv_ws_kernel(SaConvArgs a, int tiles_per_wg, int total_tiles) {
   }
 #undef WS_IDS
 }
+
+// extra cost of an utterance end, in tiles (see the kernel's range computation)
+int g_ws_bcost = 4;
 
 template <int MODE, int NT = 5, int HALO = 4, int CC = 128, int CO = CC, int SA = 1, int UU = 1>
 int launch_ws(const SaConvArgs& a, hipStream_t st) {
@@ -806,14 +847,19 @@ int launch_ws(const SaConvArgs& a, hipStream_t st) {
     attr_set = true;
   }
   const int total = args.ntiles * a.B;
-  const int per = sa_div_up(total, n_cu);
-  const int nwg = sa_div_up(total, per);
-  hipLaunchKernelGGL(kern, dim3(nwg), dim3(256), lds, st, args, per, total);
+  const int nwg = total < n_cu ? total : n_cu;
+  hipLaunchKernelGGL(kern, dim3(nwg), dim3(256), lds, st, args, g_ws_bcost, total);
   hipError_t e = hipGetLastError();
   return e == hipSuccess ? 0 : -(int)e;
 }
 
 }  // namespace
+
+extern "C" int sa_conv_ws_set_bcost(int tiles) {
+  if (tiles < 0 || tiles > 64) return -22;
+  g_ws_bcost = tiles;
+  return 0;
+}
 
 // Does the weight-stationary kernel serve this launch?  (sa_conv_gemm.hip asks before routing.)
 bool sa_conv_ws_covers(int dtype, int cin, int cout, int sa, int u, const SaConvArgs* a) {

@@ -386,9 +386,13 @@ def reduce_finalize(mode, part, nbatch, Cc, ncomp=2, count=1.0, gamma=None, beta
     out = None
     if mode != L.FIN_IN_FWD:
         rows = torch.empty(nbatch, n, dtype=torch.float64, device=dev)
-        tk = _tickets.get(dev)
-        if tk is None:                       # zero-initialised once; the kernel resets what it used
-            tk = _tickets[dev] = torch.zeros(256, dtype=torch.int32, device=dev)
+        # one ticket per 32-output chunk (sa_reduce_finalize indexes tickets[blockIdx.x]); the buffer is
+        # per (device, stream): launches on one stream are ordered, two streams must not share tickets
+        nchunk = -(-n // 32)
+        key = (dev, L.stream().value if hasattr(L.stream(), "value") else int(L.stream() or 0))
+        tk = _tickets.get(key)
+        if tk is None or tk.numel() < nchunk:   # zero-initialised once; the kernel resets what it used
+            tk = _tickets[key] = torch.zeros(max(256, nchunk), dtype=torch.int32, device=dev)
         a.rows, a.tickets = _f(rows), _f(tk)
     if mode in (L.FIN_IN_FWD, L.FIN_BN_FWD):
         out = torch.empty(4, nbatch * Cc if mode == L.FIN_IN_FWD else Cc, dtype=torch.float32, device=dev)

@@ -82,16 +82,21 @@ def main(argv):
         train, valid = (lambda epoch: train_()), (lambda epoch: valid_())
 
     class Loader:
-        """re-iterable; the epoch number seeds the shuffle (seed + epoch)"""
+        """re-iterable; the epoch number seeds the shuffle (seed + epoch).  It is the epoch counter's
+        own number, so a resumed run continues with the shuffle orders of the epochs it has not
+        seen yet instead of replaying those of epochs 1..k."""
 
-        def __init__(self, f):
-            self.f, self.epoch = f, 0
+        def __init__(self, f, counter):
+            self.f, self.counter = f, counter
 
         def __iter__(self):
-            self.epoch += 1
-            return iter(self.f(self.epoch))
+            return iter(self.f(max(1, int(self.counter.current))))
 
-    sa_brain.fit(hparams["epoch_counter"], Loader(train), Loader(valid))
+    counter = hparams["epoch_counter"]
+    sa_brain.fit(counter, Loader(train, counter), Loader(valid, counter))
+    # the library-owned communicator (SA_COMM=lib) and its side stream go before the process group
+    # that carried its id, and before interpreter teardown
+    sdist.lib_comm_destroy()
     if sdist.world_size() > 1:
         torch.distributed.destroy_process_group()
 

@@ -156,6 +156,10 @@ def test_utility_retention_reaches_the_valid_stats():
     brain = bench.build_brain(dev, "bf16x3", 3)
     brain.asr_brain = _small(torch.bfloat16).to(dev)
     brain.modules.ConvAE.pooling_noise = None
+    # (a fresh InputNormalization has no statistics: one training-mode pass in an updating epoch
+    # fills them, as the epochs before a validation stage do)
+    brain.hparams.epoch_counter.current = 1
+    brain.features(*bench.synthetic_batch(3, 7, dev, n_samples=36 * 160 * 2 - 160).sig)
     brain.hparams.epoch_counter.current = 10
     brain.modules.eval()
     brain.on_stage_start(Stage.VALID, 1)

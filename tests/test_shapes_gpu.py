@@ -110,10 +110,13 @@ def test_instance_norm_epilogue_statistics_at_scale():
 def test_bench_size_step_is_deterministic_and_cache_is_transparent():
     """BASELINE config 2 (B = 32, T = 1008) has no oracle run; properties instead: (1) the same
     step twice gives the same BITS in every output and gradient (fixed-order slab reductions, no
-    atomics); (2) the bf16 operand caches and the apply pass fused into the data-gradient
-    prologues change nothing but the summation order of the conv-bias gradients
+    atomics, fixed tile ranges in the persistent kernels); (2) the bf16 operand caches and the apply
+    pass fused into the data-gradient prologues change nothing but summation orders
     (cache_wgrad_operand=False: separate sa_ew_apply launches, operands recomputed in the wgrad
-    kernels -- same products, same order everywhere else)."""
+    kernels, and the 128 -> 128 data gradients on the one-tile kernel instead of sa_conv_wsd: same
+    products, the normalisation-backward statistics summed in another in-tile order -- 2e-7 on the
+    slabs, which the classifier branch amplifies: the gradients agree to 1e-5 rel-MSE, the outputs
+    of the forward pass bit for bit)."""
     from oracle.features import synthetic_feats
     B, T = 32, 1008
     feats = synthetic_feats(B, T, seed=5).cuda()
@@ -144,8 +147,11 @@ def test_bench_size_step_is_deterministic_and_cache_is_transparent():
             if n == 1 and k in bias_of_normed_conv:          # cache off: other reduction order
                 scale = max(float(runs[0][2][k].abs().max()), float(g[k.replace(".bias", ".weight")].abs().max()))
                 assert float((g[k] - runs[0][2][k]).abs().max()) <= 1e-4 * scale, k
-            else:
-                assert torch.equal(g[k], runs[0][2][k]), k
+            elif n == 1:                                     # cache off: statistics summed in another order
+                d = float(((g[k].double() - runs[0][2][k].double()) ** 2).sum() / (runs[0][2][k].double() ** 2).sum().clamp_min(1e-30))
+                assert d < 1e-5, (k, d)
+            else:                                            # the same step again: bit for bit
+                assert torch.equal(g[k], runs[0][2][k]), (n, k)
 
 
 @pytest.mark.parametrize("precision,limit", [("f32", 1e-8), ("bf16x3", 1e-4)])
