@@ -121,6 +121,9 @@ int sa_conv_gemm_set_impl(int impl);
  * (profiling tools name the kernel they time with it) */
 int sa_conv_gemm_route(int dtype, int cin, int cout, int sa, int u, const SaConvArgs* a);
 int sa_conv_pp_set_tile_rows(int rows);
+/* persistent kernels: extra cost of an utterance end in tiles, for the equal-cost tile ranges (tuning) */
+int sa_conv_ws_set_bcost(int tiles);
+int sa_conv_wsd_set_bcost(int tiles);
 
 /* fp32 master weights -> fragment-major MFMA operand image (K = GEMM reduction channels,
  * N = produced channels; element W(t,k,n) = src[k*sk + n*sn + t*st]).
@@ -284,6 +287,24 @@ int sa_cls_losses(const float* logp, const long long* label, int B, int NC, floa
                   float* dconf, void* stream);                   /* out = (nll, confusion) */
 int sa_cosine_loss(const float* x1, const float* x2, int B, int S, int D, float* rowloss,
                    float* loss, float* dx1, void* stream);
+
+/* The FC head (classify: Linear(256,128) ReLU BatchNorm Linear(128,64) ReLU BatchNorm Linear(64,2),
+ * models/ConvAutoEncoder.py:47-55, + log_softmax :68) as ONE forward and ONE backward launch
+ * (sa_head_fused.hip): train mode, local BatchNorm statistics, M <= sa_head_max_rows() rows.
+ * sa_head_fwd: pooled [M][256]; w / b: nn.Linear weight / bias; g / be: BatchNorm weight / bias;
+ *   rm / rv: running statistics (updated; may be NULL); outputs h1 [M][128], h2 [M][64] (post-ReLU),
+ *   f1 [4][128], f2 [4][64] (mean, rstd, scale, shift), logp [M][2].
+ * sa_head_bwd: dlogp [M][2] -> every parameter gradient (any may be NULL) and dpooled [M][256].
+ * Larger batches, eval mode and SyncBatchNorm use the separate launches above. */
+int sa_head_fwd(const float* pooled, const float* w1, const float* b1, const float* g1, const float* be1,
+                float* rm1, float* rv1, const float* w2, const float* b2, const float* g2, const float* be2,
+                float* rm2, float* rv2, const float* w3, const float* b3, float* h1, float* f1, float* h2,
+                float* f2, float* logp, int M, float eps, float momentum, void* stream);
+int sa_head_bwd(const float* dlogp, const float* logp, const float* pooled, const float* h1, const float* f1,
+                const float* h2, const float* f2, const float* w1, const float* g1, const float* w2,
+                const float* g2, const float* w3, float* dw1, float* db1, float* dg1, float* dbe1, float* dw2,
+                float* db2, float* dg2, float* dbe2, float* dw3, float* db3, float* dpooled, int M, void* stream);
+int sa_head_max_rows(void);
 
 /* x-vector gender classifier forward (models/external_gender_classifiers.py:71-115,144-183;
  * evaluator_inference.yaml:34-48): TDNN block = speechbrain Conv1d (reflect "same" padding) ->

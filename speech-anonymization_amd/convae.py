@@ -125,6 +125,9 @@ class ConvAutoencoder(nn.Module):
         # 4.02-4.08 vs 4.02 ms), so off by default; never under SyncBatchNorm (the head then
         # contains collectives).
         self.overlap_head = os.environ.get("SA_OVERLAP_HEAD", "0") == "1"
+        # the FC head as one forward and one backward launch (sa_head_fused.hip) where its BatchNorm
+        # statistics are local and B fits one workgroup; SA_FUSED_HEAD=0: the separate launches
+        self.fused_head = os.environ.get("SA_FUSED_HEAD", "1") == "1"
 
     def forward(self, feats):
         # walking the module tree costs ~0.15 ms a call: the (names, parameters) lists are cached
@@ -386,8 +389,15 @@ class _ConvAEFn(torch.autograd.Function):
                                2, 64, ps=f2[2], pt=f2[3])
             return H1, f1, H2, f2, ops.log_softmax(logits)
 
-        hs = model._head_stream(feats.device) if (model.overlap_head and not model._bn_syncs()) else None
-        if hs is None:
+        # one launch for the whole head where the batch statistics are local (train mode, no
+        # SyncBatchNorm exchange between the layers) and the batch fits one workgroup
+        fused_head = train and model.fused_head and not model._bn_syncs() and B <= ops.head_max_rows()
+        clsP = {k[len("sex_classifier.classify."):]: v for k, v in P.items() if k.startswith("sex_classifier.classify.")}
+        hs = model._head_stream(feats.device) if (model.overlap_head and not model._bn_syncs() and not fused_head) else None
+        if fused_head:
+            H1, f1, H2, f2, logp = ops.head_fwd(pooled, clsP, cls.classify[2], cls.classify[5])
+            tracked += [cls.classify[2].num_batches_tracked, cls.classify[5].num_batches_tracked]
+        elif hs is None:
             H1, f1, H2, f2, logp = head_fwd()
         else:                                  # beside the decoder's convolutions
             main = torch.cuda.current_stream()
@@ -414,7 +424,7 @@ class _ConvAEFn(torch.autograd.Function):
         S.update(x0=x0, y=[y0, y1, y2, y3, y4, y5, y6, y7, y8], r=[r0, r1, r2],
                  n=[None, n1, n2, n3, n4, None, n6, None, n8], bn=[bn_n, bn0, bn1, bn2], f=[f1, f2],
                  pooled=pooled, pmean=pmean, psd=psd, H1=H1, H2=H2, logp=logp,
-                 dims=(B, T, Ltot, L2, L4, La, Lb, Lc), train=train, W=W, A=A, gc=gc)
+                 dims=(B, T, Ltot, L2, L4, La, Lb, Lc), train=train, W=W, A=A, gc=gc, fused_head=fused_head)
         ctx.S, ctx.model, ctx.names, ctx.params = S, model, names, params
         ctx.need_input_grad = feats.requires_grad
         return recon.view(B, T, Fd), logp
@@ -621,6 +631,16 @@ class _ConvAEFn(torch.autograd.Function):
         # ======================= sex classifier: FC head =======================
         def head_bwd():
             c = "sex_classifier.classify."
+            if S.get("fused_head"):                  # the whole chain in one launch (sa_head_bwd)
+                short = ("0.weight", "0.bias", "2.weight", "2.bias", "3.weight", "3.bias", "5.weight", "5.bias",
+                         "6.weight", "6.bias")
+                views = {}
+                for k in short:
+                    if need[c + k]:
+                        views[k] = G[c + k] = newg(c + k)
+                clsP = {k: P[c + k] for k in short}
+                return ops.head_bwd(d_logp.contiguous().float(), S["logp"], S["pooled"], S["H1"], f1, S["H2"], f2,
+                                    clsP, views)
             dLG = ops.log_softmax_bwd(d_logp.contiguous().float(), S["logp"])
             H1, H2 = S["H1"], S["H2"]
             G[c + "6.weight"] = ops.dense_wgrad(dLG, H2, newg(c + "6.weight"), ps=f2[2], pt=f2[3])

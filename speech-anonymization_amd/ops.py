@@ -553,6 +553,43 @@ def dense_wgrad(dY, X, dW, ps=None, pt=None):
     return dW
 
 
+def head_max_rows():
+    return L.load().sa_head_max_rows()
+
+
+def head_fwd(pooled, P, bn1, bn2, eps=1e-5, momentum=0.1):
+    """The whole FC head in one launch (sa_head_fwd).  P: the sex_classifier.classify.* parameters by
+    short name ("0.weight" ...); bn1 / bn2: the BatchNorm modules (running statistics are updated).
+    Returns H1, f1 (mean, rstd, scale, shift), H2, f2, logp."""
+    M = pooled.shape[0]
+    dev = pooled.device
+    H1 = torch.empty(M, 128, dtype=torch.float32, device=dev)
+    H2 = torch.empty(M, 64, dtype=torch.float32, device=dev)
+    f1 = torch.empty(4, 128, dtype=torch.float32, device=dev)
+    f2 = torch.empty(4, 64, dtype=torch.float32, device=dev)
+    logp = torch.empty(M, 2, dtype=torch.float32, device=dev)
+    L.check(L.load().sa_head_fwd(_f(pooled), _f(P["0.weight"]), _f(P["0.bias"]), _f(P["2.weight"]), _f(P["2.bias"]),
+                                 _f(bn1.running_mean), _f(bn1.running_var), _f(P["3.weight"]), _f(P["3.bias"]),
+                                 _f(P["5.weight"]), _f(P["5.bias"]), _f(bn2.running_mean), _f(bn2.running_var),
+                                 _f(P["6.weight"]), _f(P["6.bias"]), _f(H1), _f(f1), _f(H2), _f(f2), _f(logp), M,
+                                 C.c_float(eps), C.c_float(momentum), L.stream()), "sa_head_fwd")
+    return H1, tuple(f1[i] for i in range(4)), H2, tuple(f2[i] for i in range(4)), logp
+
+
+def head_bwd(dlogp, logp, pooled, H1, f1, H2, f2, P, grads):
+    """sa_head_bwd: grads maps the short parameter names to fp32 gradient views (or None); returns dpooled.
+    f1 / f2: the tuples head_fwd returned (rows of one [4][N] tensor)."""
+    M = pooled.shape[0]
+    dpooled = torch.empty(M, 256, dtype=torch.float32, device=pooled.device)
+    g = lambda k: _f(grads.get(k))
+    L.check(L.load().sa_head_bwd(_f(dlogp), _f(logp), _f(pooled), _f(H1), _f(f1[0]), _f(H2), _f(f2[0]),
+                                 _f(P["0.weight"]), _f(P["2.weight"]), _f(P["3.weight"]), _f(P["5.weight"]),
+                                 _f(P["6.weight"]), g("0.weight"), g("0.bias"), g("2.weight"), g("2.bias"),
+                                 g("3.weight"), g("3.bias"), g("5.weight"), g("5.bias"), g("6.weight"), g("6.bias"),
+                                 _f(dpooled), M, L.stream()), "sa_head_bwd")
+    return dpooled
+
+
 def log_softmax(X):
     Y = torch.empty_like(X)
     L.check(L.load().sa_log_softmax(_f(X), _f(Y), X.shape[0], X.shape[1], L.stream()), "sa_log_softmax")

@@ -958,6 +958,56 @@ def test_weight_stationary_conv_kernel_random_lengths():
         ops.conv_impl()
 
 
+@pytest.mark.parametrize("B", [10, 32, 64, 3])
+def test_fused_fc_head_equals_the_separate_launches(B):
+    """sa_head_fwd / sa_head_bwd (the FC head of the sex classifier, models/ConvAutoEncoder.py:47-55,68, as
+    one forward and one backward launch) against the chain of separate launches they replace (3 dense, column
+    sums, BatchNorm finalisers, log-softmax; ~25 launches backward) and against torch autograd on the CPU:
+    outputs, BatchNorm running statistics, every parameter gradient and d pooled."""
+    from speech_anonymization_amd import ops
+    d = dev()
+    g = torch.Generator().manual_seed(B)
+    cls = torch.nn.Sequential(torch.nn.Linear(256, 128), torch.nn.ReLU(), torch.nn.BatchNorm1d(128),
+                              torch.nn.Linear(128, 64), torch.nn.ReLU(), torch.nn.BatchNorm1d(64),
+                              torch.nn.Linear(64, 2))
+    with torch.no_grad():
+        for p_ in cls.parameters():
+            p_.copy_(torch.randn(p_.shape, generator=g) * (0.3 if p_.dim() == 1 else p_.shape[1] ** -0.5))
+        cls[2].weight.add_(1.0); cls[5].weight.add_(1.0)
+    pooled = torch.randn(B, 256, generator=g)
+    dlogp = torch.randn(B, 2, generator=g) / B
+    # CPU reference (train-mode BatchNorm)
+    ref = __import__("copy").deepcopy(cls).train()
+    xr = pooled.clone().requires_grad_(True)
+    lp = torch.log_softmax(ref(xr), dim=1)
+    lp.backward(dlogp)
+    P = {k: v.detach().to(d).contiguous() for k, v in cls.state_dict().items() if v.dtype.is_floating_point and "running" not in k}
+    bn1, bn2 = __import__("copy").deepcopy(cls[2]).to(d), __import__("copy").deepcopy(cls[5]).to(d)
+    pd, dl = pooled.to(d), dlogp.to(d)
+    H1, f1, H2, f2, logp = ops.head_fwd(pd, P, bn1, bn2)
+    grads = {k: torch.full_like(v, float("nan")) for k, v in P.items()}
+    dpooled = ops.head_bwd(dl, logp, pd, H1, f1, H2, f2, P, grads)
+    torch.cuda.synchronize()
+    assert rel_mse(logp, lp) < (1e-10 if B >= 10 else 2e-9)      # (BatchNorm over 3 rows amplifies the rounding)
+    assert rel_mse(bn1.running_mean, ref[2].running_mean) < 1e-10 and rel_mse(bn1.running_var, ref[2].running_var) < 1e-10
+    assert rel_mse(bn2.running_mean, ref[5].running_mean) < 1e-10 and rel_mse(bn2.running_var, ref[5].running_var) < 1e-10
+    assert rel_mse(dpooled, xr.grad) < (1e-9 if B >= 10 else 1e-7)
+    for k, v in ref.named_parameters():
+        assert rel_mse(grads[k], v.grad) < (1e-9 if B >= 10 else 1e-7), k
+    # the separate launches (what the model runs under SyncBatchNorm, in eval mode and for B > 64)
+    sH1 = ops.dense(pd, P["0.weight"], P["0.bias"], 128, 256, relu=True)
+    b1s = __import__("copy").deepcopy(cls[2]).to(d)
+    sf1 = ops.fin_bn_fwd(ops.colsums(sH1), 128, B, P["2.weight"], P["2.bias"], b1s.running_mean, b1s.running_var)
+    sH2 = ops.dense(sH1, P["3.weight"], P["3.bias"], 64, 128, ps=sf1[2], pt=sf1[3], relu=True)
+    b2s = __import__("copy").deepcopy(cls[5]).to(d)
+    sf2 = ops.fin_bn_fwd(ops.colsums(sH2), 64, B, P["5.weight"], P["5.bias"], b2s.running_mean, b2s.running_var)
+    slogp = ops.log_softmax(ops.dense(sH2, P["6.weight"], P["6.bias"], 2, 64, ps=sf2[2], pt=sf2[3]))
+    torch.cuda.synchronize()
+    assert rel_mse(logp, slogp) < (1e-10 if B >= 10 else 2e-9) and rel_mse(H1, sH1) < 1e-11 and rel_mse(H2, sH2) < 1e-9
+    for i in range(4):
+        assert rel_mse(f1[i], sf1[i]) < 1e-10 and rel_mse(f2[i], sf2[i]) < 1e-10
+
+
 WSD_CASES = [
     # name, K, dil, pad, Lin, prologue (None | "in" | "bn"), epilogue variant, second gradient
     ("enc11", 5, 1, 2, 20160, "in", 1, False),      # InstanceNorm prologue, (acc) * swish'(z)
