@@ -61,6 +61,9 @@ def parse_args(argv=None):
                          "only if the eager region turns out host-bound on this box; the B = 10 block, which "
                          "eager cannot keep GPU-bound (3.8 ms of GPU work per step), as a replay")
     ap.add_argument("--no-graph", action="store_true", help="never replay a hipGraph (eager everywhere)")
+    ap.add_argument("--dp-graph", action="store_true",
+                    help="allow the hipGraph replay with more than one rank too (the RCCL all-reduces are "
+                         "captured with the step; rehearsed on one rank only, hence opt-in here)")
     ap.add_argument("--master-port", type=int, default=0)
     ap.add_argument("--conv-impl", default="default", choices=["default", "one-tile", "pingpong"],
                     help="A/B timing of the conv kernels (default: weight-stationary where it covers)")
@@ -210,7 +213,7 @@ def run_config(args, batch_size, rank, world, device, profile_key=None, graph=No
     from speech_anonymization_amd import ops
     ops.conv_impl(pingpong=args.conv_impl == "pingpong", ws=args.conv_impl == "default",
                   tile_rows=args.tile_rows)
-    graph = world == 1 and (args.graph if graph is None else graph)
+    graph = (world == 1 or args.dp_graph) and (args.graph if graph is None else graph)
     brain = build_brain(device, args.dtype, batch_size, hip_graph=graph)
     batch = synthetic_batch(batch_size, rank, device, args.samples)
 
@@ -324,6 +327,20 @@ def attach_pmc_traffic(roof, dtype, batch):
         pass
 
 
+def step_traffic(dtype, batch, T):
+    """HBM bytes of ONE train step summed over every kernel, from the rocprofv3 --pmc passes of this
+    configuration (profiles/pmc_traffic.json "<dtype>:B<batch>:step", written by tools/pmc_traffic.py
+    --json; a separate profiled run: `source` names it), beside the algorithmic figure of SURVEY 8(d)."""
+    try:
+        pm = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
+        e = pm["%s:B%d:step" % (dtype, batch)]
+        alg = BYTES_PER_FRAME[dtype] * batch * T
+        return {"bytes": e["total_bytes"], "read_bytes": e["read_bytes"], "write_bytes": e["write_bytes"],
+                "algorithmic_bytes": alg, "over_algorithmic": e["total_bytes"] / alg, "source": e.get("source")}
+    except Exception:
+        return None
+
+
 def main(argv=None):
     argv = sys.argv[1:] if argv is None else list(argv)
     args = parse_args(argv)
@@ -389,7 +406,7 @@ def main(argv=None):
         note(f"B={args.batch}: {value:.4g} frames/s, {elapsed / args.steps * 1e3:.3f} ms/step")
     b10 = None
     if not args.no_b10 and args.batch != 10 and args.samples == N_SAMPLES:
-        g10_want = False if args.no_graph else (True if world == 1 else None)
+        g10_want = False if args.no_graph else (True if (world == 1 or args.dp_graph) else None)
         try:
             e10, l10, _, g10, host10 = run_config(args, 10, rank, world, device, graph=g10_want)
         except Exception as exc:
@@ -423,6 +440,7 @@ def main(argv=None):
                        "batch_per_gpu": args.batch, "frames_per_utt": T, "parallelism": f"dp{world}",
                        "loss": loss, "b10": b10},
             "step_hbm_roofline_frac": value * BYTES_PER_FRAME[args.dtype] / (world * HBM_PEAK_GBS * 1e9),
+            "step_traffic": step_traffic(args.dtype, args.batch, T),
             "roofline": roof,
             "roofline_family": [{k: r[k] for k in ("kernel", "launches_timed", "avg_us", "bound", "frac", "frac_hbm",
                                                    "frac_mfma", "algorithmic_bytes", "algorithmic_flops", "traffic")}

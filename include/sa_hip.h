@@ -29,11 +29,16 @@ extern "C" {
 #define SA_BF16 1
 #define SA_BF16X3 2   /* fp32 storage, split-bf16 operands, 3 bf16 MFMAs per k-step */
 #define SA_BF16X1F 3  /* fp32 storage, operands rounded to bf16 once, 1 bf16 MFMA (sa_wgrad only) */
-#define SA_FP8 4      /* bf16 storage; MFMA operands OCP e4m3: the activation rows are quantised while
-                       * they are staged, the weight image is e4m3 scaled by a per-tensor power of two
-                       * (SaConvArgs.wscale, undone in the epilogue); fp32 accumulation and statistics.
-                       * Forward-type launches of sa_conv_gemm only (BASELINE config 5: "fp8
-                       * weights/activations"); gradients stay on SA_BF16. */
+#define SA_FP8 4      /* FORWARD-OPERAND EXPERIMENT, not a training mode and not BASELINE config 5 (which is
+                       * listed as not built: DESIGN.md 3): bf16 storage; MFMA operands OCP e4m3 -- the
+                       * activation rows are quantised unscaled while they are staged, the weight image is
+                       * e4m3 scaled by a per-tensor power of two (SaConvArgs.wscale, undone in the
+                       * epilogue); fp32 accumulation and statistics.  Forward-type launches of
+                       * sa_conv_gemm only; gradients stay on SA_BF16.  Measured: same speed as SA_BF16
+                       * (the non-scaled K = 16 fp8 MFMA runs at the bf16 rate), reconstruction 2.4e-2
+                       * off the fp32 oracle, the adversarial (classifier-branch) gradient direction lost
+                       * (cosine 0.13).  Kept because the kernel is exact against emulated e4m3 operands
+                       * (tests) and pins the e4m3 fragment layout for a block-scaled follow-up. */
 #define SA_F64 5      /* sa_comm_allreduce only: the SyncBatchNorm element counts */
 #define SA_MAX_TAPS 5
 #define SA_COMM_ID_BYTES 128

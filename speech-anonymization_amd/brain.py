@@ -127,6 +127,13 @@ class Brain:
         self.gc_freeze = bool(run_opts.get("gc_freeze", True))
         self.distributed_launch = bool(run_opts.get("distributed_launch", sdist.is_distributed()))
         self.modules = torch.nn.ModuleDict(modules or {})
+        # dp_batch_sizes (default "equal"): how the data-parallel ranks' batches relate.  The data
+        # layer deals every rank the same number of utterances per batch (data.shard_indices,
+        # DistributedSampler semantics), which lets the FC head exchange its pooled rows once and
+        # run on the global batch (ConvAutoencoder._head_plan).  A caller that shards differently
+        # passes the per-rank sizes, or None for the per-BatchNorm exchange that needs no sizes.
+        # Applied to the modules in on_fit_start.
+        self.dp_batch_sizes = run_opts.get("dp_batch_sizes", "equal")
         self.opt_class = opt_class
         self.hparams = types.SimpleNamespace(**(hparams or {}))
         self.checkpointer = checkpointer
@@ -151,6 +158,9 @@ class Brain:
         checkpoint if the output folder holds one (all ranks; model, scheduler, normaliser, epoch
         counter, optimizer moments -- reference checkpoints carry optimizer.ckpt too)."""
         self.modules.to(self.device)
+        for m in self.modules.values():
+            if hasattr(m, "dp_batch_sizes"):
+                m.dp_batch_sizes = self.dp_batch_sizes
         self.init_optimizers()
         if self.checkpointer is not None:
             if self.optimizer is not None:
@@ -418,7 +428,11 @@ class SexAnonymizationTraining(Brain):
     # host then issues one graph launch per step instead of ~230 kernel launches (at B = 10 the
     # eager step is bound by the host's launch rate).  Noam's rate and Adam's step counts live in
     # device tensors (capturable Adam); the non-finite-loss flag is read one step late from pinned
-    # memory.  Falls back to the eager path for gradient accumulation > 1 and under DDP.
+    # memory.  Data-parallel: the RCCL all-reduces (stage buckets on the side stream, statistic
+    # sums in line) are recorded with the step -- fork and join of the side stream are event edges
+    # inside the capture -- so every rank replays its own graph and the collectives meet on the
+    # wire as in the eager step (same sequence, same sizes, whichever ranks replay or run eagerly).
+    # Falls back to the eager path for gradient accumulation > 1 and on the gloo carrier.
     GRAPH_WARMUP = 3
 
     def _graph_key(self, batch):
@@ -504,7 +518,7 @@ class SexAnonymizationTraining(Brain):
 
     def fit_batch(self, batch):
         self.apply_epoch_schedule()
-        if (self.hip_graph and self.hparams.gradient_accumulation == 1 and not sdist.dp_active()
+        if (self.hip_graph and self.hparams.gradient_accumulation == 1 and sdist.capturable()
                 and self.optimizer is not None):
             return self._fit_batch_graph(batch)
         predictions = self.compute_forward(batch, Stage.TRAIN)

@@ -128,6 +128,13 @@ class ConvAutoencoder(nn.Module):
         # the FC head as one forward and one backward launch (sa_head_fused.hip) where its BatchNorm
         # statistics are local and B fits one workgroup; SA_FUSED_HEAD=0: the separate launches
         self.fused_head = os.environ.get("SA_FUSED_HEAD", "1") == "1"
+        # data-parallel FC head: None = every BatchNorm1d of the head exchanges its sums (any batch
+        # split); "equal" = every rank holds a batch as large as this one (what data.shard_indices
+        # deals); [b0, b1, ...] = the ranks' batch sizes.  With the sizes known the pooled rows are
+        # exchanged ONCE and the head runs on the global batch on every rank (_head_plan).
+        self.dp_batch_sizes = None
+        # parity probe only (see _ConvAEFn.backward): the backward re-reads bf16-rounded stored tensors
+        self.bwd_reload_bf16 = os.environ.get("SA_BWD_RELOAD_BF16", "0") == "1"
 
     def forward(self, feats):
         # walking the module tree costs ~0.15 ms a call: the (names, parameters) lists are cached
@@ -202,6 +209,31 @@ class ConvAutoencoder(nn.Module):
             return local_sums, 1
         g = local_sums.clone()
         return g, self._bn_allreduce(g)
+
+    def _head_plan(self, B):
+        """(row offset of this rank, global batch, world) when the FC head runs on the gathered
+        global batch, else None.  The two BatchNorm1d exchanges of the forward and the two of the
+        backward become one exchange of the pooled rows [B_global, 256] and one of d log p
+        [B_global, 2]; the statistics are then local sums over the global rows."""
+        if not self._bn_syncs() or self.dp_batch_sizes is None:
+            return None
+        W, r = sdist.world_size(), sdist.rank()
+        sizes = [B] * W if isinstance(self.dp_batch_sizes, str) else [int(b) for b in self.dp_batch_sizes]
+        if self.dp_batch_sizes != "equal" and isinstance(self.dp_batch_sizes, str):
+            raise SaHipError(f"dp_batch_sizes: 'equal', a list of per-rank batch sizes or None, not {self.dp_batch_sizes!r}")
+        if len(sizes) != W or sizes[r] != B:
+            raise SaHipError(f"dp_batch_sizes {sizes} does not describe rank {r} of {W} holding {B} utterances")
+        return sum(sizes[:r]), sum(sizes), W
+
+    @staticmethod
+    def _gather_rows(x, plan):
+        """[B_global, C] with every rank's rows in rank order: this rank's rows into a zeroed
+        buffer, one sum all-reduce (adds exact zeros, so the rows arrive bit-identical)."""
+        off, Bg, _ = plan
+        g = torch.zeros(Bg, x.shape[1], device=x.device, dtype=x.dtype)
+        g[off:off + x.shape[0]].copy_(x)
+        sdist.all_reduce_now(g)
+        return g
 
 
 class _W:
@@ -323,15 +355,17 @@ class _ConvAEFn(torch.autograd.Function):
             sums = ops.sum_partials(stats, 1, rows=model._bn_rows()) if train else None
             return bnorm(sums, count, mod, prefix, C, ci)
 
-        def bnorm(sums, count, mod, prefix, C, ci):
+        def bnorm(sums, count, mod, prefix, C, ci, local=False):
             """sums [C,2] local; returns (mean, rstd, scale, shift) per channel.  ci: index of
-            this BatchNorm in the all-reduced count vector gc (SyncBatchNorm)."""
+            this BatchNorm in the all-reduced count vector gc (SyncBatchNorm).  local: the sums
+            already cover the global batch (gathered head rows), nothing to exchange."""
             if not train:
                 return ops.fin_bn_eval(C, P[prefix + ".weight"], P[prefix + ".bias"],
                                        mod.running_mean, mod.running_var)
-            model._bn_allreduce(sums)
+            if not local:
+                model._bn_allreduce(sums)
             out = ops.fin_bn_fwd(sums, C, count, P[prefix + ".weight"], P[prefix + ".bias"],
-                                 mod.running_mean, mod.running_var, count_dev=cdev(ci))
+                                 mod.running_mean, mod.running_var, count_dev=None if local else cdev(ci))
             tracked.append(mod.num_batches_tracked)
             return out
 
@@ -378,32 +412,40 @@ class _ConvAEFn(torch.autograd.Function):
                                s2=bn1[2], t2=bn1[3], relu=True, want_stats=True)
         bn2 = bn_stats(st, B * Lc, cls.tdnn[8], "sex_classifier.tdnn.8", 128, 3)
         pooled, pmean, psd = ops.pool_fwd(r2, bn2[2], bn2[3], noise=_noise(model, B, feats.device))
-        def head_fwd():
-            H1 = ops.dense(pooled, P["sex_classifier.classify.0.weight"], P["sex_classifier.classify.0.bias"],
+        def head_fwd(X, n, local=False):
+            H1 = ops.dense(X, P["sex_classifier.classify.0.weight"], P["sex_classifier.classify.0.bias"],
                            128, 256, relu=True)
-            f1 = bnorm(ops.colsums(H1) if train else None, B, cls.classify[2], "sex_classifier.classify.2", 128, 4)
+            f1 = bnorm(ops.colsums(H1) if train else None, n, cls.classify[2], "sex_classifier.classify.2", 128, 4, local)
             H2 = ops.dense(H1, P["sex_classifier.classify.3.weight"], P["sex_classifier.classify.3.bias"],
                            64, 128, ps=f1[2], pt=f1[3], relu=True)
-            f2 = bnorm(ops.colsums(H2) if train else None, B, cls.classify[5], "sex_classifier.classify.5", 64, 5)
+            f2 = bnorm(ops.colsums(H2) if train else None, n, cls.classify[5], "sex_classifier.classify.5", 64, 5, local)
             logits = ops.dense(H2, P["sex_classifier.classify.6.weight"], P["sex_classifier.classify.6.bias"],
                                2, 64, ps=f2[2], pt=f2[3])
             return H1, f1, H2, f2, ops.log_softmax(logits)
 
+        # data-parallel with known per-rank batch sizes: the pooled rows of all ranks, one exchange
+        plan = model._head_plan(B) if train else None
+        head_in, Bh = (model._gather_rows(pooled, plan), plan[1]) if plan else (pooled, B)
         # one launch for the whole head where the batch statistics are local (train mode, no
         # SyncBatchNorm exchange between the layers) and the batch fits one workgroup
-        fused_head = train and model.fused_head and not model._bn_syncs() and B <= ops.head_max_rows()
+        fused_head = (train and model.fused_head and (plan is not None or not model._bn_syncs())
+                      and Bh <= ops.head_max_rows())
         clsP = {k[len("sex_classifier.classify."):]: v for k, v in P.items() if k.startswith("sex_classifier.classify.")}
-        hs = model._head_stream(feats.device) if (model.overlap_head and not model._bn_syncs() and not fused_head) else None
+        hs = (model._head_stream(feats.device) if (model.overlap_head and not model._bn_syncs() and not fused_head)
+              else None)
         if fused_head:
-            H1, f1, H2, f2, logp = ops.head_fwd(pooled, clsP, cls.classify[2], cls.classify[5])
+            H1, f1, H2, f2, logp = ops.head_fwd(head_in, clsP, cls.classify[2], cls.classify[5])
             tracked += [cls.classify[2].num_batches_tracked, cls.classify[5].num_batches_tracked]
         elif hs is None:
-            H1, f1, H2, f2, logp = head_fwd()
+            H1, f1, H2, f2, logp = head_fwd(head_in, Bh, plan is not None)
         else:                                  # beside the decoder's convolutions
             main = torch.cuda.current_stream()
             hs.wait_stream(main)
             with torch.cuda.stream(hs):
-                H1, f1, H2, f2, logp = head_fwd()
+                H1, f1, H2, f2, logp = head_fwd(head_in, Bh)
+        logp_all = logp
+        if plan:                               # this rank's rows of the global log-probabilities
+            logp = logp_all[plan[0]:plan[0] + B]
         # ---------------- decoder ----------------
         y6, st = cg(y5, pw("decoder.1.weight", "convT_fwd"), "decoder.1.weight", P["decoder.1.bias"], 128, 64, 1, 2,
                                ops.UP2, L2, want_stats=True)
@@ -416,14 +458,14 @@ class _ConvAEFn(torch.autograd.Function):
         recon = ops.convCto1(y8, P["decoder.8.weight"], P["decoder.8.bias"], n8[2], n8[3], True)
         if hs is not None:
             main.wait_stream(hs)
-            for tns in (H1, H2, logp, f1[0], f2[0]):      # allocated on the side stream, consumed on this one
+            for tns in (H1, H2, logp_all, f1[0], f2[0]):      # allocated on the side stream, consumed on this one
                 tns.record_stream(main)
 
         if tracked:
             torch._foreach_add_(tracked, 1)
         S.update(x0=x0, y=[y0, y1, y2, y3, y4, y5, y6, y7, y8], r=[r0, r1, r2],
                  n=[None, n1, n2, n3, n4, None, n6, None, n8], bn=[bn_n, bn0, bn1, bn2], f=[f1, f2],
-                 pooled=pooled, pmean=pmean, psd=psd, H1=H1, H2=H2, logp=logp,
+                 pooled=head_in, pmean=pmean, psd=psd, H1=H1, H2=H2, logp=logp_all, head_plan=plan,
                  dims=(B, T, Ltot, L2, L4, La, Lb, Lc), train=train, W=W, A=A, gc=gc, fused_head=fused_head)
         ctx.S, ctx.model, ctx.names, ctx.params = S, model, names, params
         ctx.need_input_grad = feats.requires_grad
@@ -441,6 +483,14 @@ class _ConvAEFn(torch.autograd.Function):
             raise SaHipError("backward through eval-mode BatchNorm is not implemented")
         y0, y1, y2, y3, y4, y5, y6, y7, y8 = S["y"]
         r0, r1, r2 = S["r"]
+        if model.bwd_reload_bf16:
+            # PARITY PROBE, not a mode: what bf16 side copies of the stored forward
+            # tensors would do to the gradients -- the tensors the backward only RE-READS (the
+            # normalisation-backward prologues' y, the epilogues' x) are rounded to bf16 here, the
+            # kernels and every other operand are unchanged (tools/bf16_reload_probe.py reports the result)
+            rb = lambda t_: t_.bfloat16().float() if t_ is not None and t_.dtype == torch.float32 else t_
+            y0, y1, y2, y3, y4, y5, y6, y7, y8 = (rb(t_) for t_ in (y0, y1, y2, y3, y4, y5, y6, y7, y8))
+            r0, r1, r2 = (rb(t_) for t_ in (r0, r1, r2))
         n1, n2, n3, n4, n6, n8 = S["n"][1], S["n"][2], S["n"][3], S["n"][4], S["n"][6], S["n"][8]
         bn_n, bn0, bn1, bn2 = S["bn"]
         f1, f2 = S["f"]
@@ -631,6 +681,21 @@ class _ConvAEFn(torch.autograd.Function):
         # ======================= sex classifier: FC head =======================
         def head_bwd():
             c = "sex_classifier.classify."
+            plan = S.get("head_plan")
+            dlp, Bh = d_logp.contiguous().float(), B
+            if plan:                                  # d log p of every rank's rows, one exchange
+                dlp, Bh = model._gather_rows(dlp, plan), plan[1]
+            dP = head_bwd_rows(c, dlp, Bh, plan is not None)
+            if plan:
+                # every rank now holds the head gradients of the SUM of the ranks' losses; the
+                # data-parallel average that follows expects each rank's share
+                hg = [G[k] for k in names if k.startswith(c) and k in G]
+                if plan[2] > 1 and hg:
+                    torch._foreach_mul_(hg, 1.0 / plan[2])
+                dP = dP[plan[0]:plan[0] + B]
+            return dP
+
+        def head_bwd_rows(c, dlp, n, local):
             if S.get("fused_head"):                  # the whole chain in one launch (sa_head_bwd)
                 short = ("0.weight", "0.bias", "2.weight", "2.bias", "3.weight", "3.bias", "5.weight", "5.bias",
                          "6.weight", "6.bias")
@@ -639,24 +704,23 @@ class _ConvAEFn(torch.autograd.Function):
                     if need[c + k]:
                         views[k] = G[c + k] = newg(c + k)
                 clsP = {k: P[c + k] for k in short}
-                return ops.head_bwd(d_logp.contiguous().float(), S["logp"], S["pooled"], S["H1"], f1, S["H2"], f2,
-                                    clsP, views)
-            dLG = ops.log_softmax_bwd(d_logp.contiguous().float(), S["logp"])
+                return ops.head_bwd(dlp, S["logp"], S["pooled"], S["H1"], f1, S["H2"], f2, clsP, views)
+            glob = (lambda l: l) if local else (lambda l: model._bn_global(l)[0])
+            cd = (lambda i: None) if local else cdev
+            dLG = ops.log_softmax_bwd(dlp, S["logp"])
             H1, H2 = S["H1"], S["H2"]
             G[c + "6.weight"] = ops.dense_wgrad(dLG, H2, newg(c + "6.weight"), ps=f2[2], pt=f2[3])
             G[c + "6.bias"] = newg(c + "6.bias"); ops.colsums(dLG, out0=G[c + "6.bias"])
             dN2 = ops.dense(dLG, P[c + "6.weight"], None, 64, 2, transpose_w=True)
             G[c + "5.weight"], G[c + "5.bias"] = newg(c + "5.weight"), newg(c + "5.bias")
             l2 = ops.colsums(dN2, H2, f2[0], f2[1], out0=G[c + "5.bias"], out1=G[c + "5.weight"])
-            g2s, _ = model._bn_global(l2)
-            dH2 = ops.bn2d_bwd(dN2, H2, g2s, B, P[c + "5.weight"], f2[0], f2[1], True, count_dev=cdev(5))
+            dH2 = ops.bn2d_bwd(dN2, H2, glob(l2), n, P[c + "5.weight"], f2[0], f2[1], True, count_dev=cd(5))
             G[c + "3.weight"] = ops.dense_wgrad(dH2, H1, newg(c + "3.weight"), ps=f1[2], pt=f1[3])
             G[c + "3.bias"] = newg(c + "3.bias"); ops.colsums(dH2, out0=G[c + "3.bias"])
             dN1 = ops.dense(dH2, P[c + "3.weight"], None, 128, 64, transpose_w=True)
             G[c + "2.weight"], G[c + "2.bias"] = newg(c + "2.weight"), newg(c + "2.bias")
             l1 = ops.colsums(dN1, H1, f1[0], f1[1], out0=G[c + "2.bias"], out1=G[c + "2.weight"])
-            g1s, _ = model._bn_global(l1)
-            dH1 = ops.bn2d_bwd(dN1, H1, g1s, B, P[c + "2.weight"], f1[0], f1[1], True, count_dev=cdev(4))
+            dH1 = ops.bn2d_bwd(dN1, H1, glob(l1), n, P[c + "2.weight"], f1[0], f1[1], True, count_dev=cd(4))
             G[c + "0.weight"] = ops.dense_wgrad(dH1, S["pooled"], newg(c + "0.weight"))
             G[c + "0.bias"] = newg(c + "0.bias"); ops.colsums(dH1, out0=G[c + "0.bias"])
             return ops.dense(dH1, P[c + "0.weight"], None, 256, 128, transpose_w=True)

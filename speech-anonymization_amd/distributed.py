@@ -42,6 +42,15 @@ def dp_active():
     return dist.get_world_size() > 1 or os.environ.get("SA_FORCE_DP") == "1"
 
 
+def capturable():
+    """the data-parallel exchanges can be recorded into a hipGraph: they are RCCL launches on HIP
+    streams (the library communicator, or torch.distributed's nccl backend, whose work objects stay
+    off the watchdog during capture).  gloo reduces on the host: not capturable."""
+    if not dp_active():
+        return True
+    return lib_comm_active() or dist.get_backend() == "nccl"
+
+
 def lib_comm_active():
     """the library-owned RCCL communicator is up (sa_comm_init has run in this process)"""
     from . import _lib as L

@@ -165,7 +165,10 @@ def test_against_oracle_full_tensors(dt, B, T):
         if not e < lim:
             bad.append((k, e, lim))
     assert not bad, bad
-    assert abs(loss - o_loss) < (3e-5 if dt != torch.bfloat16 else 3e-2) * max(1.0, abs(o_loss))
+    # f32: rounding only; bf16x3: north_star's 1e-4 (the 4-row BatchNorm1d of the head amplifies the
+    # operand split's ~1e-6 to a few 1e-5 on the adversarial term)
+    loss_lim = {torch.float32: 3e-5, "bf16x3": 1e-4}.get(dt, 3e-2)
+    assert abs(loss - o_loss) < loss_lim * max(1.0, abs(o_loss))
     osd, hsd = om.state_dict(), m.state_dict()
     for k in osd:
         if "running" in k:

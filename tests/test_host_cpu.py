@@ -282,3 +282,27 @@ def test_checkpoint_keep_only_find_and_average(tmp_path):
     avg = Checkpointer.average_checkpoints(ck.find_checkpoints(), recoverable_name="model")
     assert torch.allclose(avg["0.weight"], torch.full((2, 3), (1.0 + 3.0) / 2))
     assert int(avg["1.num_batches_tracked"]) == 2 and avg["1.num_batches_tracked"].dtype == torch.long
+
+
+def test_head_plan_places_the_ranks_rows(monkeypatch):
+    """ConvAutoencoder._head_plan: where this rank's rows sit in the gathered global batch of the FC
+    head (offset, global rows, world); sizes that do not describe this rank are refused."""
+    from speech_anonymization_amd import distributed as sdist
+    from speech_anonymization_amd.convae import ConvAutoencoder, SaHipError
+    m = ConvAutoencoder()
+    assert m._head_plan(4) is None                               # one process: nothing to gather
+    monkeypatch.setattr(sdist, "dp_active", lambda: True)
+    monkeypatch.setattr(sdist, "world_size", lambda: 3)
+    monkeypatch.setattr(sdist, "rank", lambda: 1)
+    assert m._head_plan(4) is None                               # sizes unknown: per-BatchNorm exchange
+    m.dp_batch_sizes = "equal"
+    assert m._head_plan(4) == (4, 12, 3)
+    m.dp_batch_sizes = [5, 4, 2]
+    assert m._head_plan(4) == (5, 11, 3)
+    for bad in ([5, 3, 2], [5, 4], "ragged"):
+        m.dp_batch_sizes = bad
+        with pytest.raises(SaHipError):
+            m._head_plan(4)
+    m.sync_bn = False
+    m.dp_batch_sizes = "equal"
+    assert m._head_plan(4) is None

@@ -1005,7 +1005,7 @@ def test_fused_fc_head_equals_the_separate_launches(B):
     torch.cuda.synchronize()
     assert rel_mse(logp, slogp) < (1e-10 if B >= 10 else 2e-9) and rel_mse(H1, sH1) < 1e-11 and rel_mse(H2, sH2) < 1e-9
     for i in range(4):
-        assert rel_mse(f1[i], sf1[i]) < 1e-10 and rel_mse(f2[i], sf2[i]) < 1e-10
+        assert rel_mse(f1[i], sf1[i]) < 1e-10 and rel_mse(f2[i], sf2[i]) < (1e-10 if B >= 10 else 2e-9)
 
 
 WSD_CASES = [

@@ -16,7 +16,8 @@ find /tmp/prof_ks /tmp/prof_fetch /tmp/prof_write /tmp/prof_sq -name "*.csv" | s
 KS=$(find /tmp/prof_ks -name "*kernel_stats.csv" | head -1)
 [ -n "$KS" ] && cp $KS $OUT/kernel_stats.csv && python3 tools/prof_summary.py $OUT/kernel_stats.csv 15 > $OUT/kernel_stats_per_step.txt
 F=$(find /tmp/prof_fetch -name "*counter_collection.csv" | head -1); W=$(find /tmp/prof_write -name "*counter_collection.csv" | head -1)
-[ -n "$F" ] && [ -n "$W" ] && python3 tools/pmc_traffic.py $F $W > $OUT/pmc_traffic.txt
+[ -n "$F" ] && [ -n "$W" ] && python3 tools/pmc_traffic.py $F $W --json $OUT/pmc_traffic.json --tag bf16x3:B32 --steps 10 \
+   --source "profiles/${TAG}_pmc_traffic_bf16x3_B32.txt (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes of this bench command, 8 set-up + 2 steps; FETCH_SIZE x2)" > $OUT/pmc_traffic.txt
 S=$(find /tmp/prof_sq -name "*counter_collection.csv" | head -1)
 [ -n "$S" ] && python3 tools/sq_summary.py $S sa_ > $OUT/sq_counters.txt
 for f in $OUT/*.log; do tail -n 2 $f | cut -c1-200; done
