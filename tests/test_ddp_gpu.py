@@ -40,7 +40,7 @@ def _run(model, feats, target, gender, parts=None):
            {k: v.detach().cpu() for k, v in model.state_dict().items() if "running" in k}
 
 
-def _worker(rank, world, port, q, cuts=(0, 3, 6), sizes=None):
+def _worker(rank, world, port, q, cuts=(0, 3, 6), sizes=None, fused_head=True):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
                       LOCAL_RANK=str(rank), SA_DIST_BACKEND="gloo", SA_SAME_DEVICE="1")
     sys.path.insert(0, ROOT)
@@ -53,6 +53,7 @@ def _worker(rank, world, port, q, cuts=(0, 3, 6), sizes=None):
     m.load_state_dict(numpy_params(8886))
     m.cuda().train()
     m.dp_batch_sizes = sizes
+    m.fused_head = fused_head
     feats, target, gender = _inputs(6, 72)
     lo, hi = cuts[rank], cuts[rank + 1]
     calls, plain_now = [0], sdist.all_reduce_now
@@ -67,21 +68,24 @@ def _worker(rank, world, port, q, cuts=(0, 3, 6), sizes=None):
     torch.distributed.destroy_process_group()
 
 
-@pytest.mark.parametrize("cuts,sizes", [((0, 3, 6), "equal"), ((0, 4, 6), [4, 2]), ((0, 3, 6), None), ((0, 4, 6), None)],
-                         ids=["3+3 global head", "4+2 global head", "3+3", "4+2"])
-def test_two_ranks_equal_one_rank_with_double_batch(cuts, sizes):
+@pytest.mark.parametrize("cuts,sizes,fused_head",
+                         [((0, 3, 6), "equal", True), ((0, 4, 6), [4, 2], True), ((0, 4, 6), [4, 2], False),
+                          ((0, 3, 6), None, True), ((0, 4, 6), None, True)],
+                         ids=["3+3 global head", "4+2 global head", "4+2 global head, separate launches", "3+3", "4+2"])
+def test_two_ranks_equal_one_rank_with_double_batch(cuts, sizes, fused_head):
     """equal shards (3 + 3) and ragged ones (4 + 2: the SyncBatchNorm element COUNTS differ per
     rank and are all-reduced beside the sums, like torch.nn.SyncBatchNorm).  "global head": the
     ranks' batch sizes are known (dp_batch_sizes), the pooled rows and d log p are exchanged once
     each and the FC head runs on the global batch -- two immediate all-reduces fewer per step than
-    the per-BatchNorm exchange, same gradients."""
+    the per-BatchNorm exchange, same gradients.  "separate launches": the head as it runs when the
+    global batch exceeds the one-workgroup kernel (8 ranks x 32 utterances)."""
     import torch.multiprocessing as mp
     from oracle.convae import numpy_params
     from speech_anonymization_amd.convae import ConvAutoencoder
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    port = 29600 + (os.getpid() % 1000) + cuts[1] + (2 if sizes is None else 0)
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, q, cuts, sizes)) for r in range(2)]
+    port = 29600 + (os.getpid() % 1000) + cuts[1] + (2 if sizes is None else 0) + (4 if not fused_head else 0)
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q, cuts, sizes, fused_head)) for r in range(2)]
     for p in procs:
         p.start()
     res = sorted([q.get(timeout=300) for _ in procs], key=lambda r: r[0])
