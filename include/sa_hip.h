@@ -359,6 +359,21 @@ int sa_fbank_normalize(const float* feats, const float* tilemax, int B, int T, i
                        int update_until_epoch, float* state, float* scratch, float* out,
                        void* stream);
 
+/* ---- element-wise passes of the frozen recogniser (sa_asr.hip; SURVEY 8f-2, models/SpeechBrain_ASR.py:16-30;
+ * bf16 storage, fp32 arithmetic; the GEMMs around them are library calls).
+ *   sa_add_layernorm_fwd: s = bf16(x + r) (r may be NULL), y = LayerNorm_d(s) * gamma + beta over rows of d
+ *     elements (d in {256, 512, 768, 1024}); s_out (the tensor the backward re-reads) and stat [rows][2] =
+ *     (mean, rstd) are optional: NULL under no_grad.  speechbrain's post-norm layers, x = norm(x + f(x)).
+ *   sa_layernorm_bwd: d s from d y, s, stat, gamma -- the gradient of both addends of the forward.
+ *   sa_reflect_pad_fwd / _bwd: F.pad(., (1, 1, 1, 1), "reflect") on the (T, F) axes of [B][T][F][C] rows
+ *     (the "same" padding of ConvolutionFrontEnd's 3 x 3 convolutions) and its adjoint; T, F >= 3. */
+int sa_add_layernorm_fwd(const void* x, const void* r, const void* gamma, const void* beta, void* y, void* s_out,
+                         float* stat, int rows, int d, float eps, void* stream);
+int sa_layernorm_bwd(const void* dy, const void* s, const float* stat, const void* gamma, void* ds, int rows,
+                     int d, void* stream);
+int sa_reflect_pad_fwd(const void* x, void* y, int B, int T, int F, int C, void* stream);
+int sa_reflect_pad_bwd(const void* dy, void* dx, int B, int T, int F, int C, void* stream);
+
 /* ---- data-parallel exchange (sa_comm.hip): what DistributedDataParallel / SyncBatchNorm do for
  * the reference once speechbrain_convae_train.py:524 (ddp_init_group) has run -- the gradient
  * average and the BatchNorm statistic sums -- as in-place RCCL all-reduces on a side stream the

@@ -23,6 +23,7 @@ data gradient of the reconstruction branch), and the original-features branch ru
 (no activations kept).  The loss itself is the library's sa_cosine_loss (losses.CosineSimilarityLoss).
 """
 import math
+import os
 
 import torch
 import torch.nn.functional as F
@@ -32,13 +33,56 @@ def _frozen(t):
     return torch.nn.Parameter(t, requires_grad=False)
 
 
+def _hip(x):
+    """the hand-written passes (csrc/sa_asr.hip) take contiguous bf16 tensors on the GPU"""
+    return x.is_cuda and x.dtype == torch.bfloat16
+
+
+class _ReflectPad(torch.autograd.Function):
+    """sa_reflect_pad_fwd / _bwd: one gather each way"""
+
+    @staticmethod
+    def forward(ctx, x):
+        from . import ops
+        return ops.reflect_pad(x.contiguous())
+
+    @staticmethod
+    def backward(ctx, dy):
+        from . import ops
+        return ops.reflect_pad_bwd(dy.contiguous())
+
+
 def _reflect_pad1(x):
     """F.pad(., (1, 1, 1, 1), mode="reflect") of the time and frequency dims of a [B, T, F, C]
-    tensor, written as two concatenations: the backward of torch's reflection_pad2d is an atomic
-    scatter (1.7 ms per call on the [B, 504, 40, 128] tensor of block 2); the backward of a
-    concatenation is two narrow adds."""
+    tensor.  On the GPU in bf16: the library's gather kernel and its adjoint.  Otherwise two
+    concatenations: the backward of torch's reflection_pad2d is an atomic scatter (1.7 ms per call on
+    the [B, 504, 40, 128] tensor of block 2); the backward of a concatenation is two narrow adds."""
+    if _hip(x):
+        return _ReflectPad.apply(x)
     x = torch.cat([x[:, :, 1:2], x, x[:, :, -2:-1]], dim=2)
     return torch.cat([x[:, 1:2], x, x[:, -2:-1]], dim=1)
+
+
+class _AddLayerNorm(torch.autograd.Function):
+    """norm(x + r) of a post-norm layer as one pass forward (sa_add_layernorm_fwd) and one backward
+    (sa_layernorm_bwd): its result is the gradient of both addends; gamma / beta are frozen."""
+
+    @staticmethod
+    def forward(ctx, x, r, gamma, beta, eps):
+        from . import ops
+        save = any(ctx.needs_input_grad[:2])
+        y, s, stat = ops.add_layernorm(x.contiguous(), None if r is None else r.contiguous(), gamma, beta, eps, save)
+        if save:
+            ctx.save_for_backward(s, stat, gamma)
+        ctx.has_r = r is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        from . import ops
+        s, stat, gamma = ctx.saved_tensors
+        ds = ops.layernorm_bwd(dy.contiguous(), s, stat, gamma)
+        return ds, (ds if ctx.has_r else None), None, None, None
 
 
 class ConvolutionFrontEnd(torch.nn.Module):
@@ -90,6 +134,11 @@ class _Attention(torch.nn.Module):
     are frozen, so the 1/sqrt(d_head) of the scores is folded into the query rows of the
     in-projection once, at construction."""
 
+    # "gemm": scores / softmax / context as separate launches on head-major copies of q, k, v;
+    # "sdpa": torch's fused attention (a library kernel, like the GEMMs) on strided head VIEWS of the
+    # packed projection -- no head-major copies, no [B, h, Tq, Tk] score tensor in HBM
+    impl = os.environ.get("SA_ASR_ATTN", "sdpa")
+
     def __init__(self, d, nhead, g):
         super().__init__()
         self.d, self.h = d, nhead
@@ -103,6 +152,18 @@ class _Attention(torch.nn.Module):
     def forward(self, x, kv=None, bias=None):
         B, Tq, d = x.shape
         h, dh = self.h, d // self.h
+        if self.impl == "sdpa" and x.is_cuda:
+            if kv is None:
+                p = F.linear(x, self.in_w, self.in_b).view(B, Tq, 3, h, dh)
+                q, k, v = p[:, :, 0].transpose(1, 2), p[:, :, 1].transpose(1, 2), p[:, :, 2].transpose(1, 2)
+            else:
+                Tk = kv.shape[1]
+                q = F.linear(x, self.in_w[:d], self.in_b[:d]).view(B, Tq, h, dh).transpose(1, 2)
+                p = F.linear(kv, self.in_w[d:], self.in_b[d:]).view(B, Tk, 2, h, dh)
+                k, v = p[:, :, 0].transpose(1, 2), p[:, :, 1].transpose(1, 2)
+            m = None if bias is None else bias.to(q.dtype).expand(B, h, Tq, k.shape[2])
+            o = F.scaled_dot_product_attention(q, k, v, attn_mask=m, scale=1.0)   # the scale sits in the query weights
+            return F.linear(o.transpose(1, 2).reshape(B, Tq, d), self.out_w, self.out_b)
         if kv is None:                                            # one head-major copy for q, k, v
             q, k, v = F.linear(x, self.in_w, self.in_b).view(B, Tq, 3, h, dh).permute(2, 0, 3, 1, 4).contiguous()
         else:
@@ -130,12 +191,16 @@ class _FFN(torch.nn.Module):
 
 
 class _LN(torch.nn.Module):
+    """LayerNorm(x + r) (r optional): the residual add and the normalisation in one pass"""
+
     def __init__(self, d):
         super().__init__()
         self.w, self.b = _frozen(torch.ones(d)), _frozen(torch.zeros(d))
 
-    def forward(self, x):
-        return F.layer_norm(x, x.shape[-1:], self.w, self.b, 1e-6)
+    def forward(self, x, r=None):
+        if _hip(x) and x.shape[-1] in (256, 512, 768, 1024) and self.w.dtype == x.dtype:
+            return _AddLayerNorm.apply(x, r, self.w, self.b, 1e-6)
+        return F.layer_norm(x if r is None else x + r, x.shape[-1:], self.w, self.b, 1e-6)
 
 
 class _EncLayer(torch.nn.Module):
@@ -144,8 +209,8 @@ class _EncLayer(torch.nn.Module):
         self.att, self.ffn, self.n1, self.n2 = _Attention(d, nhead, g), _FFN(d, d_ffn, g), _LN(d), _LN(d)
 
     def forward(self, x, bias):                                   # post-norm (normalize_before: False)
-        x = self.n1(x + self.att(x, bias=bias))
-        return self.n2(x + self.ffn(x))
+        x = self.n1(x, self.att(x, bias=bias))
+        return self.n2(x, self.ffn(x))
 
 
 class _DecLayer(torch.nn.Module):
@@ -155,9 +220,9 @@ class _DecLayer(torch.nn.Module):
         self.ffn, self.n1, self.n2, self.n3 = _FFN(d, d_ffn, g), _LN(d), _LN(d), _LN(d)
 
     def forward(self, y, mem, self_bias, mem_bias):
-        y = self.n1(y + self.self_att(y, bias=self_bias))
-        y = self.n2(y + self.cross_att(y, kv=mem, bias=mem_bias))
-        return self.n3(y + self.ffn(y))
+        y = self.n1(y, self.self_att(y, bias=self_bias))
+        y = self.n2(y, self.cross_att(y, kv=mem, bias=mem_bias))
+        return self.n3(y, self.ffn(y))
 
 
 def _sine_positions(T, d, device):

@@ -1,0 +1,265 @@
+// Element-wise passes around the GEMMs of the frozen recogniser (models/SpeechBrain_ASR.py:16-30,
+// speechbrain_configs/convae.yaml:139-158 -- ConvolutionFrontEnd + post-norm TransformerASR, d_model 768).
+// The GEMMs are library calls (hipBLASLt through torch); what surrounds them was ~30 % of the
+// branch as separate torch launches.  Here, bf16 storage / fp32 arithmetic, HBM-bound by design:
+//   sa_add_layernorm_fwd   s = bf16(x + r);  y = LayerNorm(s) * gamma + beta      (one pass: x, r in; y, s out)
+//   sa_layernorm_bwd       d s from d y, s, (mean, rstd)                            (one pass; d s is the
+//                          gradient of BOTH addends -- the residual add has no backward kernel)
+//   sa_reflect_pad_fwd/bwd "same" padding of the front end's 3x3 convolutions on [B][T][F][C] rows:
+//                          one gather each way (torch: two concatenations forward, four narrow adds back)
+// One wave per row for the LayerNorm (d = 768: three 8-byte chunks per lane, the statistics by DPP /
+// permute reductions inside the wave, no LDS, no barrier).
+#include "sa_common.h"
+
+namespace {
+
+__device__ inline float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+__device__ inline void unpack4(const uint2& u, float* f) {
+  f[0] = __uint_as_float(u.x << 16); f[1] = __uint_as_float(u.x & 0xffff0000u);
+  f[2] = __uint_as_float(u.y << 16); f[3] = __uint_as_float(u.y & 0xffff0000u);
+}
+__device__ inline uint2 pack4(const float* f) {
+  return make_uint2(sa_pack_bf16x2(f[0], f[1]), sa_pack_bf16x2(f[2], f[3]));
+}
+
+// NCH chunks of 256 elements per row (d = 256 * NCH); lane l holds elements [256 j + 4 l, +4)
+template <int NCH>
+__global__ __launch_bounds__(256) void add_ln_fwd_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ r,
+                                                         const bf16_t* __restrict__ gamma,
+                                                         const bf16_t* __restrict__ beta, bf16_t* __restrict__ y,
+                                                         bf16_t* __restrict__ s_out, float* __restrict__ stat,
+                                                         int rows, float eps) {
+  constexpr int D = 256 * NCH;
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const size_t base = (size_t)row * D + lane * 4;
+  float v[NCH][4];
+  uint2 xv[NCH], rv[NCH];
+#pragma unroll
+  for (int j = 0; j < NCH; ++j) xv[j] = *reinterpret_cast<const uint2*>(x + base + 256 * j);
+  if (r) {
+#pragma unroll
+    for (int j = 0; j < NCH; ++j) rv[j] = *reinterpret_cast<const uint2*>(r + base + 256 * j);
+  }
+  float sum = 0.f;
+#pragma unroll
+  for (int j = 0; j < NCH; ++j) {
+    unpack4(xv[j], v[j]);
+    if (r) {
+      float t[4];
+      unpack4(rv[j], t);
+      // the sum is rounded to bf16 first: the normalisation (and its backward, from the stored s)
+      // sees exactly the tensor an unfused bf16 add would have produced
+      const uint2 p = pack4((float[4]){v[j][0] + t[0], v[j][1] + t[1], v[j][2] + t[2], v[j][3] + t[3]});
+      if (s_out) *reinterpret_cast<uint2*>(s_out + base + 256 * j) = p;
+      unpack4(p, v[j]);
+    } else if (s_out) {
+      *reinterpret_cast<uint2*>(s_out + base + 256 * j) = xv[j];
+    }
+    sum += (v[j][0] + v[j][1]) + (v[j][2] + v[j][3]);
+  }
+  const float mean = wave_sum(sum) * (1.0f / D);
+  float sq = 0.f;
+#pragma unroll
+  for (int j = 0; j < NCH; ++j)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      v[j][i] -= mean;
+      sq = fmaf(v[j][i], v[j][i], sq);
+    }
+  const float rstd = rsqrtf(wave_sum(sq) * (1.0f / D) + eps);
+  if (stat && lane == 0) {
+    stat[2 * row] = mean;
+    stat[2 * row + 1] = rstd;
+  }
+#pragma unroll
+  for (int j = 0; j < NCH; ++j) {
+    float g[4], b[4], o[4];
+    unpack4(*reinterpret_cast<const uint2*>(gamma + lane * 4 + 256 * j), g);
+    unpack4(*reinterpret_cast<const uint2*>(beta + lane * 4 + 256 * j), b);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) o[i] = fmaf(v[j][i] * rstd, g[i], b[i]);
+    *reinterpret_cast<uint2*>(y + base + 256 * j) = pack4(o);
+  }
+}
+
+// d s = rstd * (g - mean(g) - xhat * mean(g * xhat)),  g = d y * gamma,  xhat = (s - mean) * rstd
+template <int NCH>
+__global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16_t* __restrict__ dy, const bf16_t* __restrict__ s,
+                                                     const float* __restrict__ stat,
+                                                     const bf16_t* __restrict__ gamma, bf16_t* __restrict__ ds,
+                                                     int rows) {
+  constexpr int D = 256 * NCH;
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const size_t base = (size_t)row * D + lane * 4;
+  const float mean = stat[2 * row], rstd = stat[2 * row + 1];
+  float g[NCH][4], xh[NCH][4];
+  uint2 dv[NCH], sv[NCH];
+#pragma unroll
+  for (int j = 0; j < NCH; ++j) {
+    dv[j] = *reinterpret_cast<const uint2*>(dy + base + 256 * j);
+    sv[j] = *reinterpret_cast<const uint2*>(s + base + 256 * j);
+  }
+  float sg = 0.f, sgx = 0.f;
+#pragma unroll
+  for (int j = 0; j < NCH; ++j) {
+    float gm[4];
+    unpack4(dv[j], g[j]);
+    unpack4(sv[j], xh[j]);
+    unpack4(*reinterpret_cast<const uint2*>(gamma + lane * 4 + 256 * j), gm);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      g[j][i] *= gm[i];
+      xh[j][i] = (xh[j][i] - mean) * rstd;
+      sg += g[j][i];
+      sgx = fmaf(g[j][i], xh[j][i], sgx);
+    }
+  }
+  const float mg = wave_sum(sg) * (1.0f / D), mgx = wave_sum(sgx) * (1.0f / D);
+#pragma unroll
+  for (int j = 0; j < NCH; ++j) {
+    float o[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) o[i] = rstd * (g[j][i] - mg - xh[j][i] * mgx);
+    *reinterpret_cast<uint2*>(ds + base + 256 * j) = pack4(o);
+  }
+}
+
+__device__ inline int reflect1(int i, int n) { return i < 0 ? -i : (i >= n ? 2 * n - 2 - i : i); }
+
+// y[b][i][j][:] = x[b][refl(i-1)][refl(j-1)][:]   ([B][T][F][C] -> [B][T+2][F+2][C]; VEC elements per thread)
+template <int VEC>
+__global__ void reflect_pad_fwd_kernel(const bf16_t* __restrict__ x, bf16_t* __restrict__ y, int T, int F, int CV,
+                                       long long total) {
+  const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= total) return;
+  const int c = (int)(idx % CV);
+  long long q = idx / CV;
+  const int j = (int)(q % (F + 2));
+  q /= (F + 2);
+  const int i = (int)(q % (T + 2));
+  const long long b = q / (T + 2);
+  const size_t src = (((size_t)b * T + reflect1(i - 1, T)) * F + reflect1(j - 1, F)) * CV + c;
+  if constexpr (VEC == 8) reinterpret_cast<uint4*>(y)[idx] = reinterpret_cast<const uint4*>(x)[src];
+  else y[idx] = x[src];
+}
+
+// adjoint: dx[b][t][f] = sum of dy over the padded positions that read (t, f)
+template <int VEC>
+__global__ void reflect_pad_bwd_kernel(const bf16_t* __restrict__ dy, bf16_t* __restrict__ dx, int T, int F, int CV,
+                                       long long total) {
+  const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= total) return;
+  const int c = (int)(idx % CV);
+  long long q = idx / CV;
+  const int f = (int)(q % F);
+  q /= F;
+  const int t = (int)(q % T);
+  const long long b = q / T;
+  int ti[3], fj[3], nt = 0, nf = 0;
+  ti[nt++] = t + 1;
+  if (t == 1) ti[nt++] = 0;
+  if (t == T - 2) ti[nt++] = T + 1;
+  fj[nf++] = f + 1;
+  if (f == 1) fj[nf++] = 0;
+  if (f == F - 2) fj[nf++] = F + 1;
+  float acc[VEC];
+#pragma unroll
+  for (int k = 0; k < VEC; ++k) acc[k] = 0.f;
+  for (int a = 0; a < nt; ++a)
+    for (int e = 0; e < nf; ++e) {
+      const size_t src = (((size_t)b * (T + 2) + ti[a]) * (F + 2) + fj[e]) * CV + c;
+      if constexpr (VEC == 8) {
+        float v[8];
+        Tr<bf16_t>::unpack(reinterpret_cast<const uint4*>(dy)[src], v);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) acc[k] += v[k];
+      } else {
+        acc[0] += (float)dy[src];
+      }
+    }
+  if constexpr (VEC == 8) reinterpret_cast<uint4*>(dx)[idx] = Tr<bf16_t>::pack(acc);
+  else dx[idx] = (bf16_t)acc[0];
+}
+
+}  // namespace
+
+extern "C" int sa_add_layernorm_fwd(const void* x, const void* r, const void* gamma, const void* beta, void* y,
+                                    void* s_out, float* stat, int rows, int d, float eps, void* stream) {
+  if (!x || !gamma || !beta || !y || rows <= 0) return -22;
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  const dim3 grid(sa_div_up(rows, 4)), block(256);
+#define SA_LN_FWD(N)                                                                                        \
+  hipLaunchKernelGGL(add_ln_fwd_kernel<N>, grid, block, 0, st, (const bf16_t*)x, (const bf16_t*)r,          \
+                     (const bf16_t*)gamma, (const bf16_t*)beta, (bf16_t*)y, (bf16_t*)s_out, stat, rows, eps)
+  switch (d) {
+    case 256: SA_LN_FWD(1); break;
+    case 512: SA_LN_FWD(2); break;
+    case 768: SA_LN_FWD(3); break;
+    case 1024: SA_LN_FWD(4); break;
+    default: return -38;
+  }
+#undef SA_LN_FWD
+  hipError_t e = hipGetLastError();
+  return e == hipSuccess ? 0 : -(int)e;
+}
+
+extern "C" int sa_layernorm_bwd(const void* dy, const void* s, const float* stat, const void* gamma, void* ds,
+                                int rows, int d, void* stream) {
+  if (!dy || !s || !stat || !gamma || !ds || rows <= 0) return -22;
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  const dim3 grid(sa_div_up(rows, 4)), block(256);
+#define SA_LN_BWD(N)                                                                                   \
+  hipLaunchKernelGGL(ln_bwd_kernel<N>, grid, block, 0, st, (const bf16_t*)dy, (const bf16_t*)s, stat, \
+                     (const bf16_t*)gamma, (bf16_t*)ds, rows)
+  switch (d) {
+    case 256: SA_LN_BWD(1); break;
+    case 512: SA_LN_BWD(2); break;
+    case 768: SA_LN_BWD(3); break;
+    case 1024: SA_LN_BWD(4); break;
+    default: return -38;
+  }
+#undef SA_LN_BWD
+  hipError_t e = hipGetLastError();
+  return e == hipSuccess ? 0 : -(int)e;
+}
+
+extern "C" int sa_reflect_pad_fwd(const void* x, void* y, int B, int T, int F, int C, void* stream) {
+  if (!x || !y || B <= 0 || T < 3 || F < 3 || C <= 0) return -22;
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  if (C % 8 == 0) {
+    const long long total = (long long)B * (T + 2) * (F + 2) * (C / 8);
+    hipLaunchKernelGGL(reflect_pad_fwd_kernel<8>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st,
+                       (const bf16_t*)x, (bf16_t*)y, T, F, C / 8, total);
+  } else {
+    const long long total = (long long)B * (T + 2) * (F + 2) * C;
+    hipLaunchKernelGGL(reflect_pad_fwd_kernel<1>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st,
+                       (const bf16_t*)x, (bf16_t*)y, T, F, C, total);
+  }
+  hipError_t e = hipGetLastError();
+  return e == hipSuccess ? 0 : -(int)e;
+}
+
+extern "C" int sa_reflect_pad_bwd(const void* dy, void* dx, int B, int T, int F, int C, void* stream) {
+  if (!dy || !dx || B <= 0 || T < 3 || F < 3 || C <= 0) return -22;
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  if (C % 8 == 0) {
+    const long long total = (long long)B * T * F * (C / 8);
+    hipLaunchKernelGGL(reflect_pad_bwd_kernel<8>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st,
+                       (const bf16_t*)dy, (bf16_t*)dx, T, F, C / 8, total);
+  } else {
+    const long long total = (long long)B * T * F * C;
+    hipLaunchKernelGGL(reflect_pad_bwd_kernel<1>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st,
+                       (const bf16_t*)dy, (bf16_t*)dx, T, F, C, total);
+  }
+  hipError_t e = hipGetLastError();
+  return e == hipSuccess ? 0 : -(int)e;
+}

@@ -242,8 +242,9 @@ def conv_gemm(x, wp, bias, cin, cout, sa, u, phases, Lout, s1=None, t1=None, s2=
         tname = {L.F32: "float", L.BF16: "bf16_t", L.BF16X3: "bf16x3_t", L.BF16X1F: "bf16x1f_t", L.FP8: "fp8_t"}[kc]
         ws_mode = (5 if s2 is not None else 0) if s1 is None else 3 if want_pro_stats else 4 if s2 is not None else 1
         offs = [o for ph in phases for o, _ in ph]
-        wsd_ep = 0 if not ep else (4 if ep.get("g2") is not None else 1) if int(ep["mode"]) == 1 else (3 if ep.get("xp_is_act") else 2)
-        kind = (f"sa_conv_wsd_kernel<{ntap},{max(offs) - min(offs)},{2 if nb else 0},{wsd_ep}> ({tname}, {cin}->{cout})" if route == 3 else
+        # (the five instances <taps, span, prologue, epilogue> of the fused data-gradient kernel are ONE
+        # kernel for the roofline record: same source, same structure, 1 launch per step each)
+        kind = (f"sa_conv_wsd_kernel ({tname}, {cin}->{cout}; 5 instances)" if route == 3 else
                 f"sa_conv_ws_kernel<{ws_mode},{ntap}> ({tname}, {cin}->{cout})" if route == 2 else
                 f"sa_conv_pp_kernel<{tname},{cin},{cout},{sa},{u}>" if route == 1 else
                 f"sa_conv_gemm_kernel<{tname},{cin},{cout},{sa},{u}{',nb prologue' if nb else ''}>")
@@ -658,3 +659,40 @@ def cluster_mi(X, y, idx=None, ncls=2, k=3):
     L.check(lib.sa_cluster_mi(_f(X), _f(y), _f(idx), iters, n, X.shape[1], ncls, k, _f(mi), L.stream()),
             "sa_cluster_mi")
     return mi
+
+
+# ---- element-wise passes of the frozen recogniser (csrc/sa_asr.hip; asr.py) ----
+def add_layernorm(x, r, gamma, beta, eps, save):
+    """y = LayerNorm(bf16(x + r)) * gamma + beta over the last dimension (r may be None); bf16 tensors.
+    save: also return the stored sum s and the statistics the backward re-reads."""
+    d = x.shape[-1]
+    rows = x.numel() // d
+    y = torch.empty_like(x)
+    s = torch.empty_like(x) if save else None
+    stat = torch.empty(rows, 2, dtype=torch.float32, device=x.device) if save else None
+    L.check(L.load().sa_add_layernorm_fwd(_f(x), _f(r), _f(gamma), _f(beta), _f(y), _f(s), _f(stat), rows, d,
+                                          C.c_float(eps), L.stream()), "sa_add_layernorm_fwd")
+    return y, s, stat
+
+
+def layernorm_bwd(dy, s, stat, gamma):
+    d = s.shape[-1]
+    ds = torch.empty_like(s)
+    L.check(L.load().sa_layernorm_bwd(_f(dy), _f(s), _f(stat), _f(gamma), _f(ds), s.numel() // d, d, L.stream()),
+            "sa_layernorm_bwd")
+    return ds
+
+
+def reflect_pad(x):
+    """[B, T, F, C] bf16 -> [B, T + 2, F + 2, C], reflect padding of T and F by one"""
+    B, T, F_, Cc = x.shape
+    y = torch.empty(B, T + 2, F_ + 2, Cc, dtype=x.dtype, device=x.device)
+    L.check(L.load().sa_reflect_pad_fwd(_f(x), _f(y), B, T, F_, Cc, L.stream()), "sa_reflect_pad_fwd")
+    return y
+
+
+def reflect_pad_bwd(dy):
+    B, T2, F2, Cc = dy.shape
+    dx = torch.empty(B, T2 - 2, F2 - 2, Cc, dtype=dy.dtype, device=dy.device)
+    L.check(L.load().sa_reflect_pad_bwd(_f(dy), _f(dx), B, T2 - 2, F2 - 2, Cc, L.stream()), "sa_reflect_pad_bwd")
+    return dx

@@ -185,3 +185,83 @@ def test_utility_retention_reaches_the_valid_stats():
     brain.on_stage_end(Stage.VALID, 0.5, 1)
     assert abs(brain.valid_stats["Utility_Retention"] - float(want.mean())) < 2e-5
     assert 0.0 < brain.valid_stats["Utility_Retention"] < 1.0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("d,rows", [(768, 8064), (256, 37), (1024, 5)])
+def test_add_layernorm_kernels_equal_torch(d, rows):
+    """sa_add_layernorm_fwd / sa_layernorm_bwd (csrc/sa_asr.hip) against F.layer_norm of the bf16 sum:
+    forward within one bf16 rounding, input gradient (the same for both addends) within bf16 noise."""
+    import torch.nn.functional as F
+    torch.manual_seed(d + rows)
+    dev = torch.device("cuda:0")
+    x = torch.randn(rows, d, device=dev).bfloat16().requires_grad_()
+    r = (0.5 * torch.randn(rows, d, device=dev)).bfloat16().requires_grad_()
+    w = (1.0 + 0.1 * torch.randn(d, device=dev)).bfloat16()
+    b = (0.1 * torch.randn(d, device=dev)).bfloat16()
+    dy = torch.randn(rows, d, device=dev).bfloat16()
+    y = A._AddLayerNorm.apply(x, r, w, b, 1e-6)
+    y.backward(dy)
+    gx, gr = x.grad.clone(), r.grad.clone()
+    assert torch.equal(gx, gr)
+    xs = (x.detach() + r.detach()).float().requires_grad_()           # the bf16 sum, then fp32 arithmetic
+    yr = F.layer_norm(xs, (d,), w.float(), b.float(), 1e-6)
+    yr.backward(dy.float())
+
+    def rel(a, bb):
+        return float(((a.float() - bb.float()) ** 2).sum() / (bb.float() ** 2).sum())
+    assert rel(y, yr) < 2e-5 and rel(gx, xs.grad) < 2e-5              # bf16 rounding of the outputs: ~2^-9 rms
+    # no residual, no gradient: plain LayerNorm, nothing saved
+    with torch.no_grad():
+        y0 = A._AddLayerNorm.apply(x.detach(), None, w, b, 1e-6)
+    assert rel(y0, F.layer_norm(x.detach().float(), (d,), w.float(), b.float(), 1e-6)) < 2e-5
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("shape", [(2, 9, 7, 1), (3, 16, 10, 8), (2, 3, 3, 16), (1, 40, 20, 128)])
+def test_reflect_pad_kernels_equal_torch(shape):
+    """sa_reflect_pad_fwd / _bwd against F.pad(mode="reflect") and its autograd adjoint"""
+    import torch.nn.functional as F
+    torch.manual_seed(sum(shape))
+    dev = torch.device("cuda:0")
+    x = torch.randn(*shape, device=dev).bfloat16().requires_grad_()
+    y = A._reflect_pad1(x)
+    xr = x.detach().float().requires_grad_()
+    yr = F.pad(xr.permute(0, 3, 1, 2), (1, 1, 1, 1), mode="reflect").permute(0, 2, 3, 1)
+    assert torch.equal(y.float(), yr)
+    dy = torch.randn_like(y)
+    y.backward(dy)
+    yr.backward(dy.float())
+    assert float((x.grad.float() - xr.grad).abs().max()) <= 0.02 * float(xr.grad.abs().max())   # bf16 sum of <= 4 terms
+
+
+@pytest.mark.gpu
+def test_fused_attention_equals_the_explicit_form():
+    """asr._Attention: torch's fused attention on strided head views ("sdpa", default) against the explicit
+    GEMM / softmax form on head-major copies, self- and cross-attention with padding masks, forward and
+    input gradient (bf16)."""
+    torch.manual_seed(3)
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(5)
+    att = A._Attention(768, 8, g).to(dev).bfloat16()
+    B, Tq, Tk = 3, 40, 56
+    x = torch.randn(B, Tq, 768, device=dev).bfloat16()
+    mem = torch.randn(B, Tk, 768, device=dev).bfloat16()
+    pad = torch.zeros(B, Tk, dtype=torch.bool, device=dev)
+    pad[1, 30:] = True
+    bias = A.TransformerASR._key_bias(pad)
+    self_bias = torch.full((Tq, Tq), float("-inf"), device=dev).triu(1)[None, None]
+    out = {}
+    for impl in ("gemm", "sdpa"):
+        att.impl = impl
+        xa, xb = x.clone().requires_grad_(), x.clone().requires_grad_()
+        o1 = att(xa, bias=self_bias)
+        o2 = att(xb, kv=mem, bias=bias)
+        (o1.float().pow(2).sum() + o2.float().pow(2).sum()).backward()
+        out[impl] = (o1, o2, xa.grad, xb.grad)
+    A._Attention.impl = "sdpa"
+
+    def rel(a, b):
+        return float(((a.float() - b.float()) ** 2).sum() / (b.float() ** 2).sum())
+    for a, b in zip(out["sdpa"], out["gemm"]):
+        assert rel(a, b) < 1e-3, rel(a, b)                            # two bf16 pipelines: ~1e-5 .. 1e-4

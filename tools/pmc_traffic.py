@@ -71,6 +71,7 @@ if "--json" in opts:
                        "FETCH_SIZE x2 (gfx950 wide-read correction); written by tools/pmc_traffic.py --json from the `source` "
                        "of each entry.  Keys: <dtype>:B<batch>:<bench.py kernel label>; <dtype>:B<batch>:step = one train step.")
     tot_r = tot_w = 0.0
+    wsd = [0, 0.0, 0.0]                       # the instances of the fused data-gradient kernel as one record
     for k in fetch:
         n, f = fetch[k]
         w = write.get(k, [n, 0.0])[1]
@@ -80,6 +81,12 @@ if "--json" in opts:
         if lab:
             out[f"{tag}:{lab}"] = {"read_bytes": 2 * f * 1024 / n, "write_bytes": w * 1024 / n,
                                    "total_bytes": (2 * f + w) * 1024 / n, "launches": n, "source": src}
+        if "sa_conv_wsd_kernel<" in k:
+            wsd = [wsd[0] + n, wsd[1] + 2 * f * 1024, wsd[2] + w * 1024]
+    if wsd[0]:
+        out[f"{tag}:sa_conv_wsd_kernel (bf16x3_t, 128->128; 5 instances)"] = {
+            "read_bytes": wsd[1] / wsd[0], "write_bytes": wsd[2] / wsd[0], "total_bytes": (wsd[1] + wsd[2]) / wsd[0],
+            "launches": wsd[0], "source": src}
     out[f"{tag}:step"] = {"read_bytes": tot_r / nsteps, "write_bytes": tot_w / nsteps, "total_bytes": (tot_r + tot_w) / nsteps,
                           "steps": nsteps, "source": src}
     json.dump(out, open(opts["--json"], "w"), indent=1)
