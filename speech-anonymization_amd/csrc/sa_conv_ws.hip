@@ -262,11 +262,6 @@ void sa_conv_ws_kernel(SaConvArgs a, int bcost, int total_tiles) {
     asm volatile("" : "+s"(r));
     return r;
   };
-  auto row_block = [&](const void* p, int b, int L, int row, int row_bytes) {
-    const char* r = reinterpret_cast<const char*>(p) + (long)(b * L + row) * row_bytes;   // B*L rows < 2^31 (checked at launch)
-    asm volatile("" : "+s"(r));
-    return r;
-  };
   auto dma_piece = [&](Tile T, bool edge, int j, int part = 2) {
     const int i = wave_ + 4 * j;
     if (j == WS_DPW - 1 && i >= WS_NDMA) return;
