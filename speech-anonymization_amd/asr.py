@@ -128,6 +128,22 @@ class ConvolutionFrontEnd(torch.nn.Module):
         return x                                                  # [B, T', F', C]
 
 
+def _sdpa_mask(bias, B, h, Tq, Tk, dtype):
+    """additive mask [B | 1, 1, Tq | 1, Tk] -> what the fused attention kernel takes without copying it
+    again: materialised [B, h, Tq, Tk] in the operand dtype inside a buffer whose rows are padded to a
+    multiple of 8 elements (torch pads an unaligned mask on EVERY call otherwise: 18 us x 100 per step).
+    Built once per forward and shared by the layers (the caller caches it on the bias tensor)."""
+    cache = bias.__dict__.setdefault("_sa_sdpa", {}) if hasattr(bias, "__dict__") else {}
+    key = (B, h, Tq, Tk, dtype)
+    m = cache.get(key)
+    if m is None:
+        buf = torch.empty(B, h, Tq, -(-Tk // 8) * 8, dtype=dtype, device=bias.device)
+        m = buf[..., :Tk]
+        m.copy_(bias.expand(B, h, Tq, Tk))
+        cache[key] = m
+    return m
+
+
 class _Attention(torch.nn.Module):
     """multi-head attention as library GEMMs (packed in-projection, scores, context, out-projection);
     the softmax accumulates in fp32.  kv=None: self-attention with the QKV GEMM packed.  The weights
@@ -153,15 +169,15 @@ class _Attention(torch.nn.Module):
         B, Tq, d = x.shape
         h, dh = self.h, d // self.h
         if self.impl == "sdpa" and x.is_cuda:
+            # unbind, not three selects: its backward is ONE stack into the packed gradient (a select's is a
+            # zero-filled tensor per operand plus the adds that merge them)
             if kv is None:
-                p = F.linear(x, self.in_w, self.in_b).view(B, Tq, 3, h, dh)
-                q, k, v = p[:, :, 0].transpose(1, 2), p[:, :, 1].transpose(1, 2), p[:, :, 2].transpose(1, 2)
+                q, k, v = (t.transpose(1, 2) for t in F.linear(x, self.in_w, self.in_b).view(B, Tq, 3, h, dh).unbind(2))
             else:
                 Tk = kv.shape[1]
                 q = F.linear(x, self.in_w[:d], self.in_b[:d]).view(B, Tq, h, dh).transpose(1, 2)
-                p = F.linear(kv, self.in_w[d:], self.in_b[d:]).view(B, Tk, 2, h, dh)
-                k, v = p[:, :, 0].transpose(1, 2), p[:, :, 1].transpose(1, 2)
-            m = None if bias is None else bias.to(q.dtype).expand(B, h, Tq, k.shape[2])
+                k, v = (t.transpose(1, 2) for t in F.linear(kv, self.in_w[d:], self.in_b[d:]).view(B, Tk, 2, h, dh).unbind(2))
+            m = None if bias is None else _sdpa_mask(bias, B, h, Tq, k.shape[2], q.dtype)
             o = F.scaled_dot_product_attention(q, k, v, attn_mask=m, scale=1.0)   # the scale sits in the query weights
             return F.linear(o.transpose(1, 2).reshape(B, Tq, d), self.out_w, self.out_b)
         if kv is None:                                            # one head-major copy for q, k, v
