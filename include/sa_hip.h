@@ -371,6 +371,13 @@ int sa_add_layernorm_fwd(const void* x, const void* r, const void* gamma, const 
                          float* stat, int rows, int d, float eps, void* stream);
 int sa_layernorm_bwd(const void* dy, const void* s, const float* stat, const void* gamma, void* ds, int rows,
                      int d, void* stream);
+/* sa_ln_leaky_fwd / _bwd: the front end's LayerNorm over (frequency, channel) + LeakyReLU in one pass each way;
+ *   rows of d in {5120, 10240} elements (-ENOSYS otherwise); the backward recomputes the activation's branch
+ *   from x and stat, so only x (the convolution's output) and [rows][2] statistics are kept. */
+int sa_ln_leaky_fwd(const void* x, const void* gamma, const void* beta, void* y, float* stat, int rows, int d,
+                    float eps, float slope, void* stream);
+int sa_ln_leaky_bwd(const void* dy, const void* x, const float* stat, const void* gamma, const void* beta, void* dx,
+                    int rows, int d, float slope, void* stream);
 int sa_reflect_pad_fwd(const void* x, void* y, int B, int T, int F, int C, void* stream);
 int sa_reflect_pad_bwd(const void* dy, void* dx, int B, int T, int F, int C, void* stream);
 

@@ -123,9 +123,34 @@ class ConvolutionFrontEnd(torch.nn.Module):
                 xin, w = x.permute(0, 3, 1, 2), w.contiguous(memory_format=torch.channels_last)
             x = F.conv2d(xin, w, self.b[i].to(x.dtype), stride=s)
             x = x.permute(0, 2, 3, 1).contiguous()                # [B, T', F', C] (no copy when NHWC)
-            x = F.layer_norm(x, x.shape[2:], self.ln_w[i].to(x.dtype), self.ln_b[i].to(x.dtype), 1e-5)
-            x = F.leaky_relu(x, 0.01)
+            lw, lb = self.ln_w[i], self.ln_b[i]
+            if _hip(x) and lw.dtype == x.dtype and lw.numel() in (5120, 10240):
+                x = _LNLeaky.apply(x, lw, lb, 1e-5, 0.01)
+            else:
+                x = F.leaky_relu(F.layer_norm(x, x.shape[2:], lw.to(x.dtype), lb.to(x.dtype), 1e-5), 0.01)
         return x                                                  # [B, T', F', C]
+
+
+class _LNLeaky(torch.autograd.Function):
+    """the front end's LayerNorm over (frequency, channel) + LeakyReLU: one pass each way
+    (sa_ln_leaky_fwd / _bwd); keeps the convolution's output and two floats per row"""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, eps, slope):
+        from . import ops
+        x = x.contiguous()
+        save = ctx.needs_input_grad[0]
+        y, stat = ops.ln_leaky(x, gamma, beta, eps, slope, save)
+        if save:
+            ctx.save_for_backward(x, stat, gamma, beta)
+        ctx.slope = slope
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        from . import ops
+        x, stat, gamma, beta = ctx.saved_tensors
+        return ops.ln_leaky_bwd(dy.contiguous(), x, stat, gamma, beta, ctx.slope), None, None, None, None
 
 
 def _sdpa_mask(bias, B, h, Tq, Tk, dtype):

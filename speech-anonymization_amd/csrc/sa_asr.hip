@@ -133,6 +133,106 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16_t* __restrict__ 
   }
 }
 
+// ---- front end: LayerNorm over (frequency, channel) + LeakyReLU, rows of d = 1024 * NCH elements, one
+// 256-thread workgroup per row (thread t holds elements [1024 j + 4 t, +4))
+__device__ inline float block_sum(float v, float* red) {
+  v = wave_sum(v);
+  __syncthreads();                       // (red is reused by the next reduction)
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+  __syncthreads();
+  return (red[0] + red[1]) + (red[2] + red[3]);
+}
+
+template <int NCH>
+__global__ __launch_bounds__(256) void ln_leaky_fwd_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ gamma,
+                                                           const bf16_t* __restrict__ beta, bf16_t* __restrict__ y,
+                                                           float* __restrict__ stat, float eps, float slope) {
+  constexpr int D = 1024 * NCH;
+  __shared__ float red[4];
+  const size_t base = (size_t)blockIdx.x * D + threadIdx.x * 4;
+  float v[NCH][4];
+  uint2 xv[NCH];
+#pragma unroll
+  for (int j = 0; j < NCH; ++j) xv[j] = *reinterpret_cast<const uint2*>(x + base + 1024 * j);
+  float sum = 0.f;
+#pragma unroll
+  for (int j = 0; j < NCH; ++j) {
+    unpack4(xv[j], v[j]);
+    sum += (v[j][0] + v[j][1]) + (v[j][2] + v[j][3]);
+  }
+  const float mean = block_sum(sum, red) * (1.0f / D);
+  float sq = 0.f;
+#pragma unroll
+  for (int j = 0; j < NCH; ++j)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      v[j][i] -= mean;
+      sq = fmaf(v[j][i], v[j][i], sq);
+    }
+  const float rstd = rsqrtf(block_sum(sq, red) * (1.0f / D) + eps);
+  if (stat && threadIdx.x == 0) {
+    stat[2 * blockIdx.x] = mean;
+    stat[2 * blockIdx.x + 1] = rstd;
+  }
+#pragma unroll
+  for (int j = 0; j < NCH; ++j) {
+    float g[4], b[4], o[4];
+    unpack4(*reinterpret_cast<const uint2*>(gamma + threadIdx.x * 4 + 1024 * j), g);
+    unpack4(*reinterpret_cast<const uint2*>(beta + threadIdx.x * 4 + 1024 * j), b);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const float z = fmaf(v[j][i] * rstd, g[i], b[i]);
+      o[i] = z > 0.f ? z : z * slope;
+    }
+    *reinterpret_cast<uint2*>(y + base + 1024 * j) = pack4(o);
+  }
+}
+
+// d x of y = leaky(LayerNorm(x) * gamma + beta): the activation's branch is recomputed from x and the statistics
+template <int NCH>
+__global__ __launch_bounds__(256) void ln_leaky_bwd_kernel(const bf16_t* __restrict__ dy, const bf16_t* __restrict__ x,
+                                                           const float* __restrict__ stat,
+                                                           const bf16_t* __restrict__ gamma,
+                                                           const bf16_t* __restrict__ beta, bf16_t* __restrict__ dx,
+                                                           float slope) {
+  constexpr int D = 1024 * NCH;
+  __shared__ float red[4];
+  const size_t base = (size_t)blockIdx.x * D + threadIdx.x * 4;
+  const float mean = stat[2 * blockIdx.x], rstd = stat[2 * blockIdx.x + 1];
+  float g[NCH][4], xh[NCH][4];
+  uint2 dv[NCH], sv[NCH];
+#pragma unroll
+  for (int j = 0; j < NCH; ++j) {
+    dv[j] = *reinterpret_cast<const uint2*>(dy + base + 1024 * j);
+    sv[j] = *reinterpret_cast<const uint2*>(x + base + 1024 * j);
+  }
+  float sg = 0.f, sgx = 0.f;
+#pragma unroll
+  for (int j = 0; j < NCH; ++j) {
+    float gm[4], bt[4];
+    unpack4(dv[j], g[j]);
+    unpack4(sv[j], xh[j]);
+    unpack4(*reinterpret_cast<const uint2*>(gamma + threadIdx.x * 4 + 1024 * j), gm);
+    unpack4(*reinterpret_cast<const uint2*>(beta + threadIdx.x * 4 + 1024 * j), bt);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      xh[j][i] = (xh[j][i] - mean) * rstd;
+      const float z = fmaf(xh[j][i], gm[i], bt[i]);
+      g[j][i] *= (z > 0.f ? 1.0f : slope) * gm[i];
+      sg += g[j][i];
+      sgx = fmaf(g[j][i], xh[j][i], sgx);
+    }
+  }
+  const float mg = block_sum(sg, red) * (1.0f / D), mgx = block_sum(sgx, red) * (1.0f / D);
+#pragma unroll
+  for (int j = 0; j < NCH; ++j) {
+    float o[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) o[i] = rstd * (g[j][i] - mg - xh[j][i] * mgx);
+    *reinterpret_cast<uint2*>(dx + base + 1024 * j) = pack4(o);
+  }
+}
+
 __device__ inline int reflect1(int i, int n) { return i < 0 ? -i : (i >= n ? 2 * n - 2 - i : i); }
 
 // y[b][i][j][:] = x[b][refl(i-1)][refl(j-1)][:]   ([B][T][F][C] -> [B][T+2][F+2][C]; VEC elements per thread)
@@ -260,6 +360,40 @@ extern "C" int sa_reflect_pad_bwd(const void* dy, void* dx, int B, int T, int F,
     hipLaunchKernelGGL(reflect_pad_bwd_kernel<1>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st,
                        (const bf16_t*)dy, (bf16_t*)dx, T, F, C, total);
   }
+  hipError_t e = hipGetLastError();
+  return e == hipSuccess ? 0 : -(int)e;
+}
+
+extern "C" int sa_ln_leaky_fwd(const void* x, const void* gamma, const void* beta, void* y, float* stat, int rows,
+                               int d, float eps, float slope, void* stream) {
+  if (!x || !gamma || !beta || !y || rows <= 0) return -22;
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+#define SA_LL_FWD(N)                                                                                          \
+  hipLaunchKernelGGL(ln_leaky_fwd_kernel<N>, dim3(rows), dim3(256), 0, st, (const bf16_t*)x, (const bf16_t*)gamma, \
+                     (const bf16_t*)beta, (bf16_t*)y, stat, eps, slope)
+  switch (d) {
+    case 5120: SA_LL_FWD(5); break;
+    case 10240: SA_LL_FWD(10); break;
+    default: return -38;
+  }
+#undef SA_LL_FWD
+  hipError_t e = hipGetLastError();
+  return e == hipSuccess ? 0 : -(int)e;
+}
+
+extern "C" int sa_ln_leaky_bwd(const void* dy, const void* x, const float* stat, const void* gamma, const void* beta,
+                               void* dx, int rows, int d, float slope, void* stream) {
+  if (!dy || !x || !stat || !gamma || !beta || !dx || rows <= 0) return -22;
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+#define SA_LL_BWD(N)                                                                                            \
+  hipLaunchKernelGGL(ln_leaky_bwd_kernel<N>, dim3(rows), dim3(256), 0, st, (const bf16_t*)dy, (const bf16_t*)x, stat, \
+                     (const bf16_t*)gamma, (const bf16_t*)beta, (bf16_t*)dx, slope)
+  switch (d) {
+    case 5120: SA_LL_BWD(5); break;
+    case 10240: SA_LL_BWD(10); break;
+    default: return -38;
+  }
+#undef SA_LL_BWD
   hipError_t e = hipGetLastError();
   return e == hipSuccess ? 0 : -(int)e;
 }

@@ -696,3 +696,22 @@ def reflect_pad_bwd(dy):
     dx = torch.empty(B, T2 - 2, F2 - 2, Cc, dtype=dy.dtype, device=dy.device)
     L.check(L.load().sa_reflect_pad_bwd(_f(dy), _f(dx), B, T2 - 2, F2 - 2, Cc, L.stream()), "sa_reflect_pad_bwd")
     return dx
+
+
+def ln_leaky(x, gamma, beta, eps, slope, save):
+    """leaky_relu(LayerNorm over the trailing gamma.numel() elements): [rows, d] bf16, d in {5120, 10240}"""
+    d = gamma.numel()
+    rows = x.numel() // d
+    y = torch.empty_like(x)
+    stat = torch.empty(rows, 2, dtype=torch.float32, device=x.device) if save else None
+    L.check(L.load().sa_ln_leaky_fwd(_f(x), _f(gamma), _f(beta), _f(y), _f(stat), rows, d, C.c_float(eps),
+                                     C.c_float(slope), L.stream()), "sa_ln_leaky_fwd")
+    return y, stat
+
+
+def ln_leaky_bwd(dy, x, stat, gamma, beta, slope):
+    d = gamma.numel()
+    dx = torch.empty_like(x)
+    L.check(L.load().sa_ln_leaky_bwd(_f(dy), _f(x), _f(stat), _f(gamma), _f(beta), _f(dx), x.numel() // d, d,
+                                     C.c_float(slope), L.stream()), "sa_ln_leaky_bwd")
+    return dx

@@ -265,3 +265,26 @@ def test_fused_attention_equals_the_explicit_form():
         return float(((a.float() - b.float()) ** 2).sum() / (b.float() ** 2).sum())
     for a, b in zip(out["sdpa"], out["gemm"]):
         assert rel(a, b) < 1e-3, rel(a, b)                            # two bf16 pipelines: ~1e-5 .. 1e-4
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("fc", [(40, 128), (20, 512)])
+def test_layernorm_leakyrelu_kernels_equal_torch(fc):
+    """sa_ln_leaky_fwd / _bwd (the front end's LayerNorm over (frequency, channel) + LeakyReLU) against
+    F.layer_norm + F.leaky_relu in fp32 on the same bf16 input"""
+    import torch.nn.functional as F
+    torch.manual_seed(fc[0])
+    dev = torch.device("cuda:0")
+    x = torch.randn(3, 11, *fc, device=dev).bfloat16().requires_grad_()
+    w = (1.0 + 0.1 * torch.randn(*fc, device=dev)).bfloat16()
+    b = (0.2 * torch.randn(*fc, device=dev)).bfloat16()
+    dy = torch.randn(3, 11, *fc, device=dev).bfloat16()
+    y = A._LNLeaky.apply(x, w, b, 1e-5, 0.01)
+    y.backward(dy)
+    xr = x.detach().float().requires_grad_()
+    yr = F.leaky_relu(F.layer_norm(xr, fc, w.float(), b.float(), 1e-5), 0.01)
+    yr.backward(dy.float())
+
+    def rel(a, bb):
+        return float(((a.float() - bb.float()) ** 2).sum() / (bb.float() ** 2).sum())
+    assert rel(y, yr) < 2e-5 and rel(x.grad, xr.grad) < 2e-5
