@@ -83,3 +83,18 @@ def test_weight_stationary_kernel_isa_audit():
         pytest.skip("hipcc not installed")
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "ws_audit.py")], capture_output=True, text=True, timeout=900)
     assert r.returncode == 0 and "audit: clean" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+
+
+def test_fused_data_gradient_kernel_isa_audit():
+    """sa_conv_wsd.hip keeps loads in flight across hand-scheduled slots into registers the compiler must not
+    know (v240..v255 / a240..a255): every build is audited on the ISA -- no scratch in the tile loop, the
+    accumulator blocks untouched while they accumulate and read no sooner than three MFMAs after the last
+    write, the reserved registers named by no compiler instruction and covered by the kernel descriptor, no
+    compiler-inserted s_waitcnt vmcnt in the fast body (tools/wsd_audit.py; cross-compiles, no GPU needed)."""
+    import shutil
+    import subprocess
+    import sys
+    if not shutil.which("/opt/rocm/bin/hipcc"):
+        pytest.skip("hipcc not installed")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "wsd_audit.py")], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0 and "audit: clean" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
