@@ -135,6 +135,11 @@ class ConvAutoencoder(nn.Module):
         self.dp_batch_sizes = None
         # parity probe only (see _ConvAEFn.backward): the backward re-reads bf16-rounded stored tensors
         self.bwd_reload_bf16 = os.environ.get("SA_BWD_RELOAD_BF16", "0") == "1"
+        # PARITY PROBE, not a mode (tools/bf16_reload_probe.py): what storing the convolution outputs in
+        # bf16 would do -- 1: every stored forward tensor is rounded to bf16 right after the launch that
+        # produced it (its statistics still come from the fp32 accumulators, operands stay split);
+        # 2: the data gradients between the backward launches as well
+        self.store_bf16_probe = int(os.environ.get("SA_STORE_BF16_PROBE", "0"))
 
     def forward(self, feats):
         # walking the module tree costs ~0.15 ms a call: the (names, parameters) lists are cached
@@ -283,6 +288,14 @@ def _conv(x, w, *args, **kw):
     return ops.conv_gemm(x, w.img, *args, code=w.code, **kw)
 
 
+def _round_first(out):
+    """store_bf16_probe: the launch's main output as a bf16-stored tensor would hold it"""
+    y = out[0] if isinstance(out, tuple) else out
+    if torch.is_tensor(y) and y.dtype == torch.float32:
+        y.copy_(y.bfloat16())
+    return out
+
+
 class _PendingApply:
     """d z of a normalised layer together with the coefficients of d y = c1*dz + c2*y + c3 that the
     next data-gradient convolution applies in its prologue (instead of a sa_ew_apply pass)."""
@@ -333,7 +346,12 @@ class _ConvAEFn(torch.autograd.Function):
         def cg(x, w, key, *args, **kw):
             if cache_a and key is not None and P[key].requires_grad:
                 A[key] = kw["a_out"] = torch.empty(x.shape, dtype=torch.bfloat16, device=x.device)
-            return _conv(x, w, *args, **kw)
+            out = _conv(x, w, *args, **kw)
+            if model.store_bf16_probe:
+                y_ = out[0] if isinstance(out, tuple) else out
+                if y_.dtype == torch.float32:
+                    y_.copy_(y_.bfloat16())
+            return out
 
         ff = model.fused_finalize
 
@@ -378,6 +396,8 @@ class _ConvAEFn(torch.autograd.Function):
         cdev = lambda i: None if gc is None else gc[i:i + 1]
         # ---------------- encoder ----------------
         y0 = ops.conv1toC(x0, P["encoder.0.weight"], P["encoder.0.bias"], dt)
+        if model.store_bf16_probe and y0.dtype == torch.float32:
+            y0.copy_(y0.bfloat16())
         y1, st = cg(y0, pw("encoder.2.weight", "conv_fwd"), "encoder.2.weight", P["encoder.2.bias"], 32, 64, 2, 1,
                                ops.taps_conv(K5, 1, 2), L2, swish=True, want_stats=True)
         n1 = inorm(st, L2, "encoder.3", 64)
@@ -523,6 +543,11 @@ class _ConvAEFn(torch.autograd.Function):
             """data-gradient / forward-type launch; a _PendingApply input selects the
             normalisation-backward prologue, which also emits the bf16 d y for the deferred weight
             gradients and the column sums for the bias gradient."""
+            if model.store_bf16_probe >= 2:
+                return _round_first(cg_(gin, w, *args, **kw))
+            return cg_(gin, w, *args, **kw)
+
+        def cg_(gin, w, *args, **kw):
             if not isinstance(gin, _PendingApply):
                 return _conv(gin, w, *args, **kw)
             p = gin

@@ -22,16 +22,22 @@ target = feats + 0.1 * torch.from_numpy(rs.standard_normal((B, T, 80)).astype("f
 gender = torch.arange(B) % 2
 params = numpy_params(8886)
 o_recon, o_logp, o_loss, o_grads, _ = run_oracle(params, feats, target, gender, "l1")
-res = {}
-for probe in (False, True):
+res, outs = {}, {}
+VARIANTS = [("fp32 storage (shipped)", False, 0), ("bf16 re-reads in backward", True, 0),
+            ("bf16-stored activations", False, 1), ("bf16-stored activations + gradients", False, 2)]
+for name, reload_, store in VARIANTS:
     m = hip_model("bf16x3", params)
-    m.bwd_reload_bf16 = probe
+    m.bwd_reload_bf16, m.store_bf16_probe = reload_, store
     recon, logp, loss, grads = run_hip(m, feats, target, gender, "l1")
-    res[probe] = {k: rel_mse(grads[k], o_grads[k]) for k in o_grads if k not in NULL_BIAS}
-worst = lambda d, pred: max((v, k) for k, v in d.items() if pred(k))
-for name, pred in (("decoder", lambda k: k.startswith("decoder")), ("encoder", lambda k: k.startswith("encoder")),
-                   ("sex_classifier", lambda k: k.startswith("sex_classifier"))):
-    a, b = worst(res[False], pred), worst(res[True], pred)
-    print(f"{name:15s} worst grad rel-MSE vs fp32 oracle: fp32 re-reads {a[0]:.2e} ({a[1]})   bf16 re-reads {b[0]:.2e} ({b[1]})")
-over = [(k, v) for k, v in res[True].items() if v >= 1e-4]
-print("bf16 re-reads: gradients over the 1e-4 bar:", over if over else "none")
+    res[name] = {k: rel_mse(grads[k], o_grads[k]) for k in o_grads if k not in NULL_BIAS}
+    outs[name] = (rel_mse(recon, o_recon), rel_mse(logp, o_logp), abs(loss - o_loss))
+groups = (("decoder", lambda k: k.startswith("decoder")), ("encoder", lambda k: k.startswith("encoder")),
+          ("sex_classifier", lambda k: k.startswith("sex_classifier")))
+print(f"shape: B={B}, T={T}; rel-MSE against the fp32 CPU oracle; north_star's bar is 1e-4")
+for name, _, _ in VARIANTS:
+    r = res[name]
+    line = "  ".join("%s %.2e (%s)" % (g, *max((v, k) for k, v in r.items() if pred(k))) for g, pred in groups)
+    over = sorted(((v, k) for k, v in r.items() if v >= 1e-4), reverse=True)
+    print(f"{name:38s} recon {outs[name][0]:.2e}  logp {outs[name][1]:.2e}  |loss diff| {outs[name][2]:.1e}")
+    print(f"{'':38s} worst gradient per stage: {line}")
+    print(f"{'':38s} gradients over the bar: {[(k, float('%.3g' % v)) for v, k in over] if over else 'none'}")
