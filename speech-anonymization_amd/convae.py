@@ -138,7 +138,7 @@ class ConvAutoencoder(nn.Module):
         # PARITY PROBE, not a mode (tools/bf16_reload_probe.py): what storing the convolution outputs in
         # bf16 would do -- 1: every stored forward tensor is rounded to bf16 right after the launch that
         # produced it (its statistics still come from the fp32 accumulators, operands stay split);
-        # 2: the data gradients between the backward launches as well
+        # 2: the data gradients between the backward launches as well; 3: those gradients only
         self.store_bf16_probe = int(os.environ.get("SA_STORE_BF16_PROBE", "0"))
 
     def forward(self, feats):
@@ -347,7 +347,7 @@ class _ConvAEFn(torch.autograd.Function):
             if cache_a and key is not None and P[key].requires_grad:
                 A[key] = kw["a_out"] = torch.empty(x.shape, dtype=torch.bfloat16, device=x.device)
             out = _conv(x, w, *args, **kw)
-            if model.store_bf16_probe:
+            if model.store_bf16_probe in (1, 2):
                 y_ = out[0] if isinstance(out, tuple) else out
                 if y_.dtype == torch.float32:
                     y_.copy_(y_.bfloat16())
@@ -396,7 +396,7 @@ class _ConvAEFn(torch.autograd.Function):
         cdev = lambda i: None if gc is None else gc[i:i + 1]
         # ---------------- encoder ----------------
         y0 = ops.conv1toC(x0, P["encoder.0.weight"], P["encoder.0.bias"], dt)
-        if model.store_bf16_probe and y0.dtype == torch.float32:
+        if model.store_bf16_probe in (1, 2) and y0.dtype == torch.float32:
             y0.copy_(y0.bfloat16())
         y1, st = cg(y0, pw("encoder.2.weight", "conv_fwd"), "encoder.2.weight", P["encoder.2.bias"], 32, 64, 2, 1,
                                ops.taps_conv(K5, 1, 2), L2, swish=True, want_stats=True)
@@ -755,6 +755,8 @@ class _ConvAEFn(torch.autograd.Function):
         def tdnn_bwd(dP):
             t = "sex_classifier.tdnn."
             g, st = ops.pool_bwd(r2, bn2[2], bn2[3], dP, S["pmean"], S["psd"], bn=(bn2[0], bn2[1]))
+            if model.store_bf16_probe >= 2:
+                _round_first(g)
             g = bn_finish(g, st, r2, bn2, Lc, t + "8", t + "6.bias", 3)
             conv_wgrad(t + "6.weight", r1, g, 128, 128, 1, Lc, 3, 3, 0, s2=bn1[2], t2=bn1[3])
             g, st = cg(g, pw(t + "6.weight", "conv_dgrad"), None, 128, 128, 1, 1,
@@ -786,6 +788,8 @@ class _ConvAEFn(torch.autograd.Function):
                                                     s1=n8[2], t1=n8[3], swish=True)
             g, st = ops.conv1toC(g_rec, P["decoder.8.weight"], None, dt, flip=True, want_stats=True,
                                  ep=dict(x=y8, s1=n8[2], t1=n8[3], mean=n8[0], rstd=n8[1]))     # d z8
+            if model.store_bf16_probe >= 2:
+                _round_first(g)
             g = in_finish(g, st, y8, n8, 32, Ltot, "decoder.6", "decoder.5.bias")               # d y8
             convT_wgrad("decoder.5.weight", y7, g, 64, 32, L2)
             g, st = cg(g, pw("decoder.5.weight", "convT_dgrad"), None, 32, 64, 2, 1,
