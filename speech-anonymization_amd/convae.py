@@ -138,7 +138,8 @@ class ConvAutoencoder(nn.Module):
         # PARITY PROBE, not a mode (tools/bf16_reload_probe.py): what storing the convolution outputs in
         # bf16 would do -- 1: every stored forward tensor is rounded to bf16 right after the launch that
         # produced it (its statistics still come from the fp32 accumulators, operands stay split);
-        # 2: the data gradients between the backward launches as well; 3: those gradients only
+        # 2: the data gradients between the backward launches as well; 3: those gradients only;
+        # 4: the decoder's stored outputs and the gradients of the decoder's backward only
         self.store_bf16_probe = int(os.environ.get("SA_STORE_BF16_PROBE", "0"))
 
     def forward(self, feats):
@@ -347,7 +348,7 @@ class _ConvAEFn(torch.autograd.Function):
             if cache_a and key is not None and P[key].requires_grad:
                 A[key] = kw["a_out"] = torch.empty(x.shape, dtype=torch.bfloat16, device=x.device)
             out = _conv(x, w, *args, **kw)
-            if model.store_bf16_probe in (1, 2):
+            if model.store_bf16_probe in (1, 2) or (model.store_bf16_probe == 4 and str(key).startswith("decoder")):
                 y_ = out[0] if isinstance(out, tuple) else out
                 if y_.dtype == torch.float32:
                     y_.copy_(y_.bfloat16())
@@ -543,9 +544,11 @@ class _ConvAEFn(torch.autograd.Function):
             """data-gradient / forward-type launch; a _PendingApply input selects the
             normalisation-backward prologue, which also emits the bf16 d y for the deferred weight
             gradients and the column sums for the bias gradient."""
-            if model.store_bf16_probe >= 2:
+            if model.store_bf16_probe in (2, 3) or (model.store_bf16_probe == 4 and in_decoder[0]):
                 return _round_first(cg_(gin, w, *args, **kw))
             return cg_(gin, w, *args, **kw)
+
+        in_decoder = [False]
 
         def cg_(gin, w, *args, **kw):
             if not isinstance(gin, _PendingApply):
@@ -755,7 +758,7 @@ class _ConvAEFn(torch.autograd.Function):
         def tdnn_bwd(dP):
             t = "sex_classifier.tdnn."
             g, st = ops.pool_bwd(r2, bn2[2], bn2[3], dP, S["pmean"], S["psd"], bn=(bn2[0], bn2[1]))
-            if model.store_bf16_probe >= 2:
+            if model.store_bf16_probe in (2, 3):
                 _round_first(g)
             g = bn_finish(g, st, r2, bn2, Lc, t + "8", t + "6.bias", 3)
             conv_wgrad(t + "6.weight", r1, g, 128, 128, 1, Lc, 3, 3, 0, s2=bn1[2], t2=bn1[3])
@@ -790,6 +793,7 @@ class _ConvAEFn(torch.autograd.Function):
                                  ep=dict(x=y8, s1=n8[2], t1=n8[3], mean=n8[0], rstd=n8[1]))     # d z8
             if model.store_bf16_probe >= 2:
                 _round_first(g)
+            in_decoder[0] = True
             g = in_finish(g, st, y8, n8, 32, Ltot, "decoder.6", "decoder.5.bias")               # d y8
             convT_wgrad("decoder.5.weight", y7, g, 64, 32, L2)
             g, st = cg(g, pw("decoder.5.weight", "convT_dgrad"), None, 32, 64, 2, 1,
@@ -807,6 +811,7 @@ class _ConvAEFn(torch.autograd.Function):
             side_join()
             if need_stage["decoder"]:
                 buckets.reduce_stage("decoder")
+            in_decoder[0] = False
             return g
 
         hs = (model._head_stream(dev) if (model.overlap_head and run_decoder and not model._bn_syncs()

@@ -25,7 +25,8 @@ o_recon, o_logp, o_loss, o_grads, _ = run_oracle(params, feats, target, gender, 
 res, outs = {}, {}
 VARIANTS = [("fp32 storage (shipped)", False, 0), ("bf16 re-reads in backward", True, 0),
             ("bf16-stored activations", False, 1), ("bf16-stored activations + gradients", False, 2),
-            ("bf16-stored gradients only", False, 3)]
+            ("bf16-stored gradients only", False, 3),
+            ("bf16-stored decoder tensors (activations + gradients)", False, 4)]
 for name, reload_, store in VARIANTS:
     m = hip_model("bf16x3", params)
     m.bwd_reload_bf16, m.store_bf16_probe = reload_, store
@@ -39,6 +40,6 @@ for name, _, _ in VARIANTS:
     r = res[name]
     line = "  ".join("%s %.2e (%s)" % (g, *max((v, k) for k, v in r.items() if pred(k))) for g, pred in groups)
     over = sorted(((v, k) for k, v in r.items() if v >= 1e-4), reverse=True)
-    print(f"{name:38s} recon {outs[name][0]:.2e}  logp {outs[name][1]:.2e}  |loss diff| {outs[name][2]:.1e}")
-    print(f"{'':38s} worst gradient per stage: {line}")
-    print(f"{'':38s} gradients over the bar: {len(over)}" + (f", worst {[(k, float('%.3g' % v)) for v, k in over[:4]]}" if over else ""))
+    print(f"{name:54s} recon {outs[name][0]:.2e}  logp {outs[name][1]:.2e}  |loss diff| {outs[name][2]:.1e}")
+    print(f"{'':54s} worst gradient per stage: {line}")
+    print(f"{'':54s} gradients over the bar: {len(over)}" + (f", worst {[(k, float('%.3g' % v)) for v, k in over[:4]]}" if over else ""))
