@@ -70,8 +70,9 @@ def _worker(rank, world, port, q, cuts=(0, 3, 6), sizes=None, fused_head=True):
 
 @pytest.mark.parametrize("cuts,sizes,fused_head",
                          [((0, 3, 6), "equal", True), ((0, 4, 6), [4, 2], True), ((0, 4, 6), [4, 2], False),
-                          ((0, 3, 6), None, True), ((0, 4, 6), None, True)],
-                         ids=["3+3 global head", "4+2 global head", "4+2 global head, separate launches", "3+3", "4+2"])
+                          ((0, 3, 6), None, True), ((0, 4, 6), None, True), ((0, 2, 3, 5, 6), [2, 1, 2, 1], True)],
+                         ids=["3+3 global head", "4+2 global head", "4+2 global head, separate launches", "3+3", "4+2",
+                              "2+1+2+1 global head (four ranks)"])
 def test_two_ranks_equal_one_rank_with_double_batch(cuts, sizes, fused_head):
     """equal shards (3 + 3) and ragged ones (4 + 2: the SyncBatchNorm element COUNTS differ per
     rank and are all-reduced beside the sums, like torch.nn.SyncBatchNorm).  "global head": the
@@ -85,7 +86,8 @@ def test_two_ranks_equal_one_rank_with_double_batch(cuts, sizes, fused_head):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = 29600 + (os.getpid() % 1000) + cuts[1] + (2 if sizes is None else 0) + (4 if not fused_head else 0)
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, q, cuts, sizes, fused_head)) for r in range(2)]
+    world = len(cuts) - 1
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q, cuts, sizes, fused_head)) for r in range(world)]
     for p in procs:
         p.start()
     res = sorted([q.get(timeout=300) for _ in procs], key=lambda r: r[0])
@@ -96,7 +98,7 @@ def test_two_ranks_equal_one_rank_with_double_batch(cuts, sizes, fused_head):
     m.load_state_dict(numpy_params(8886))
     m.cuda().train()
     feats, target, gender = _inputs(6, 72)
-    ref, ref_bufs = _run(m, feats, target, gender, parts=[(cuts[0], cuts[1]), (cuts[1], cuts[2])])
+    ref, ref_bufs = _run(m, feats, target, gender, parts=[(cuts[i], cuts[i + 1]) for i in range(world)])
 
     def rel(a, b):
         a, b = torch.as_tensor(a).double(), b.double()
@@ -105,13 +107,14 @@ def test_two_ranks_equal_one_rank_with_double_batch(cuts, sizes, fused_head):
     for k, g in ref.items():
         if k in NULL_BIAS:
             continue
-        assert np.array_equal(res[0][1][k], res[1][1][k]), k        # both ranks hold the average
+        for r in range(1, world):
+            assert np.array_equal(res[0][1][k], res[r][1][k]), k    # every rank holds the average
         assert rel(res[0][1][k], g) < 2e-5, (k, rel(res[0][1][k], g))
     for k, v in ref_bufs.items():                                    # SyncBN: global statistics
         assert rel(res[0][2][k], v) < 1e-8, k
     # immediate (main-stream) exchanges of one step: the counts + 6 BatchNorm sums forward and 6
     # backward; the global head replaces 2 + 2 of them by 1 + 1
-    assert res[0][3] == res[1][3] == (13 if sizes is None else 11), res[0][3]
+    assert all(r[3] == (13 if sizes is None else 11) for r in res), [r[3] for r in res]
 
 
 def _rccl_worker(port, q, carrier, sizes="equal"):
