@@ -104,7 +104,7 @@ typedef struct SaConvArgs {
 } SaConvArgs;
 
 int sa_conv_gemm(int dtype, int cin, int cout, int sa, int u, const SaConvArgs* a, void* stream);
-/* sizeof(SaConvArgs | SaWgradArgs | SaEwArgs | SaPackDesc | SaTaps | SaFinArgs) for which = 0..5: lets a binding
+/* sizeof(SaConvArgs | SaWgradArgs | SaEwArgs | SaPackDesc | SaTaps | SaFinArgs | SaBiasMulti) for which = 0..6: lets a binding
  * verify its mirror of these records (the library reads every field) */
 int sa_abi_sizeof(int which);
 int sa_conv_gemm_ntiles(int cin, int cout, int u, int Lout);
@@ -254,6 +254,18 @@ typedef struct SaFinArgs {
   float* dgamma; float* dbeta; float* db; float* run_mean; float* run_var;
 } SaFinArgs;
 int sa_reduce_finalize(const SaFinArgs* a, void* stream);
+/* Bias gradients of several layers at once (the end of a backward stage): for each of the n <= SA_BIAS_MAX
+ * records, db[c] = sum over the nbatch x nslab slabs of part[b][s][c][0] (part [nbatch][nslab][C][ncomp] fp32,
+ * the per-tile statistics or column-sum slabs of a data-gradient launch) -- what sa_sum_partials + sa_fin_bias do
+ * for one layer, same summation order and bits, as TWO launches for all records (rows: fp64 scratch
+ * [nbatch][C] per record). */
+#define SA_BIAS_MAX 8
+typedef struct SaBiasDesc {
+  const float* part; double* rows; float* db;
+  int nbatch, nslab, C, ncomp;
+} SaBiasDesc;
+typedef struct SaBiasMulti { int n, pad_; SaBiasDesc d[SA_BIAS_MAX]; } SaBiasMulti;
+int sa_bias_multi(const SaBiasMulti* m, void* stream);
 
 /* ---- classifier head + losses (sa_head.hip): TDNNSexClassifier.forward reshape + pooling
  * (models/ConvAutoEncoder.py:61-66), classify (:47-55), log_softmax (:68); losses at

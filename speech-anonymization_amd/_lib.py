@@ -74,6 +74,17 @@ class SaFinArgs(C.Structure):
 
 
 FIN_IN_FWD, FIN_IN_BWD, FIN_BN_FWD, FIN_BN_BWD, FIN_BIAS = 1, 2, 3, 4, 5
+BIAS_MAX = 8
+
+
+class SaBiasDesc(C.Structure):
+    _fields_ = [("part", vp), ("rows", vp), ("db", vp),
+                ("nbatch", C.c_int), ("nslab", C.c_int), ("C", C.c_int), ("ncomp", C.c_int)]
+
+
+class SaBiasMulti(C.Structure):
+    _fields_ = [("n", C.c_int), ("pad_", C.c_int), ("d", SaBiasDesc * BIAS_MAX)]
+
 
 # every symbol include/sa_hip.h declares (checked by tests/test_abi.py on CPU)
 SYMBOLS = [
@@ -89,7 +100,7 @@ SYMBOLS = [
     "sa_leaky_affine_bwd", "sa_cluster_mi", "sa_fbank", "sa_fbank_table_elems", "sa_fbank_ntiles", "sa_fbank_scratch_bytes", "sa_fbank_normalize",
     "sa_comm_unique_id", "sa_comm_init", "sa_comm_world", "sa_comm_allreduce", "sa_comm_allreduce_inline", "sa_comm_join", "sa_comm_ncalls",
     "sa_comm_destroy", "sa_head_fwd", "sa_head_bwd", "sa_head_max_rows", "sa_conv_ws_set_bcost", "sa_conv_wsd_set_bcost",
-    "sa_add_layernorm_fwd", "sa_layernorm_bwd", "sa_reflect_pad_fwd", "sa_reflect_pad_bwd", "sa_ln_leaky_fwd", "sa_ln_leaky_bwd",
+    "sa_add_layernorm_fwd", "sa_layernorm_bwd", "sa_reflect_pad_fwd", "sa_reflect_pad_bwd", "sa_ln_leaky_fwd", "sa_ln_leaky_bwd", "sa_bias_multi",
 ]
 
 _lib = None
@@ -110,7 +121,7 @@ def load():
         _lib = C.CDLL(LIB_PATH)
         for s in SYMBOLS:
             getattr(_lib, s).restype = C.c_int
-        for i, rec in enumerate((SaConvArgs, SaWgradArgs, SaEwArgs, SaPackDesc, SaTaps, SaFinArgs)):
+        for i, rec in enumerate((SaConvArgs, SaWgradArgs, SaEwArgs, SaPackDesc, SaTaps, SaFinArgs, SaBiasMulti)):
             if _lib.sa_abi_sizeof(i) != C.sizeof(rec):
                 raise SaHipError(f"{rec.__name__}: binding has {C.sizeof(rec)} bytes, {LIB_PATH} "
                                  f"{_lib.sa_abi_sizeof(i)} -- rebuild the library (stale build?)")

@@ -128,6 +128,9 @@ class ConvAutoencoder(nn.Module):
         # the FC head as one forward and one backward launch (sa_head_fused.hip) where its BatchNorm
         # statistics are local and B fits one workgroup; SA_FUSED_HEAD=0: the separate launches
         self.fused_head = os.environ.get("SA_FUSED_HEAD", "1") == "1"
+        # bias gradients of a backward stage as two launches at the end of the stage (sa_bias_multi)
+        # instead of sa_sum_partials + sa_fin_bias per layer
+        self.batch_bias = os.environ.get("SA_BATCH_BIAS", "1") == "1"
         # data-parallel FC head: None = every BatchNorm1d of the head exchanges its sums (any batch
         # split); "equal" = every rank holds a batch as large as this one (what data.shard_indices
         # deals); [b0, b1, ...] = the ranks' batch sizes.  With the sizes known the pooled rows are
@@ -565,6 +568,9 @@ class _ConvAEFn(torch.autograd.Function):
                 nb_, nt_, cc_ = cs.shape
                 if ff:
                     G[p.bias_key] = ops.reduce_finalize(L.FIN_BIAS, cs, nb_, cc_, ncomp=1, db=newg(p.bias_key))
+                elif model.batch_bias:
+                    G[p.bias_key] = newg(p.bias_key)
+                    pending_bias.append((cs, nb_, cc_, 1, G[p.bias_key]))
                 else:
                     G[p.bias_key] = ops.fin_bias(ops.sum_partials(cs.view(nb_, nt_, cc_, 1), nb_), nb_, cc_,
                                                  newg(p.bias_key), ncomp=1)
@@ -577,8 +583,20 @@ class _ConvAEFn(torch.autograd.Function):
             if need[key]:
                 if ff:
                     G[key] = ops.reduce_finalize(L.FIN_BIAS, stats, B, C, db=newg(key))
+                elif model.batch_bias:
+                    G[key] = newg(key)
+                    pending_bias.append((stats, B, C, 2, G[key]))
                 else:
                     G[key] = ops.fin_bias(ops.sum_partials(stats, B), B, C, newg(key))
+
+        # bias gradients wait for the end of their stage: nothing reads them before the stage's
+        # bucket is reduced, so all of a stage's slab sums run as two launches (sa_bias_multi)
+        pending_bias = []
+
+        def flush_bias():
+            if pending_bias:
+                ops.bias_multi(pending_bias)
+                pending_bias.clear()
 
         def in_ep(y, nrm, g2=None):
             """fused-epilogue description of an [InstanceNorm -> swish] backward (stats pass)."""
@@ -699,6 +717,7 @@ class _ConvAEFn(torch.autograd.Function):
             d_logp = torch.zeros(B, 2, device=dev)
 
         def finish():
+            flush_bias()
             buckets.join()
             ctx.S = None
             grads = tuple(G[k] if need[k] else None for k in names)
@@ -776,6 +795,7 @@ class _ConvAEFn(torch.autograd.Function):
                        ops.taps_conv_dgrad_s1(5, 1, 0), L4, want_stats=True, ep=bn_ep(y4, bn_n, xp4))
             da = bn_finish(g, st, y4, bn_n, L4, "sex_classifier.norm", None, 0, xp=xp4)      # includes GRL
             side_join()
+            flush_bias()
             if need_stage["sex_classifier"]:
                 buckets.reduce_stage("sex_classifier")
             return da
@@ -809,6 +829,7 @@ class _ConvAEFn(torch.autograd.Function):
             bias_from(st, "decoder.0.bias", 128)
             conv_wgrad("decoder.0.weight", y4, g, 128, 128, 1, L4, K5, 1, 2, s1=n4[2], t1=n4[3], swish=True)
             side_join()
+            flush_bias()
             if need_stage["decoder"]:
                 buckets.reduce_stage("decoder")
             in_decoder[0] = False
@@ -861,6 +882,7 @@ class _ConvAEFn(torch.autograd.Function):
         if ctx.need_input_grad:
             d_feats = ops.convCto1(g, P["encoder.0.weight"], None, flip=True).view(B, T, 80)
         side_join()
+        flush_bias()
         if need_stage["encoder"]:
             buckets.reduce_stage("encoder")
         buckets.join()

@@ -666,6 +666,7 @@ extern "C" int sa_abi_sizeof(int which) {
     case 3: return (int)sizeof(SaPackDesc);
     case 4: return (int)sizeof(SaTaps);
     case 5: return (int)sizeof(SaFinArgs);
+    case 6: return (int)sizeof(SaBiasMulti);
     default: return -22;
   }
 }

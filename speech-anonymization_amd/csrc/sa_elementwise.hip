@@ -417,6 +417,61 @@ extern "C" int sa_fin_bias(const double* sums, int B, int C, int ncomp, float* d
 }
 
 // ---------------------------------------------------------------------------------
+// sa_bias_multi: the bias gradients of all layers of a backward stage in two launches (they are
+// needed by nobody before the stage's gradients are reduced / the optimizer runs, so their
+// ~2 x 12 launches per step leave the critical chain of the backward).  Level 1 = sa_sum_partials
+// restricted to component 0 of every channel, level 2 = sa_fin_bias: same lanes, same order, same bits.
+// ---------------------------------------------------------------------------------
+__global__ __launch_bounds__(32 * SA_SP_LANES) void sa_bias_multi_l1_kernel(SaBiasMulti m) {
+  __shared__ double part[SA_SP_LANES][33];
+  const SaBiasDesc& d = m.d[blockIdx.z];
+  const int bb = blockIdx.y, o = threadIdx.x & 31, q = threadIdx.x >> 5;
+  const int i = blockIdx.x * 32 + o;
+  if (bb >= d.nbatch || blockIdx.x * 32 >= d.C) return;          // (uniform per workgroup)
+  double s = 0.0;
+  const int n = d.C * d.ncomp;
+  if (i < d.C) {
+    const float* p = d.part + (size_t)bb * d.nslab * n + (size_t)i * d.ncomp;
+#pragma unroll 16
+    for (int k = q; k < d.nslab; k += SA_SP_LANES) s += (double)p[(size_t)k * n];
+  }
+  part[q][o] = s;
+  __syncthreads();
+  if (q == 0 && i < d.C) {
+    double t = 0.0;
+#pragma unroll
+    for (int r = 0; r < SA_SP_LANES; ++r) t += part[r][o];
+    d.rows[(size_t)bb * d.C + i] = t;
+  }
+}
+
+__global__ void sa_bias_multi_l2_kernel(SaBiasMulti m) {
+  const SaBiasDesc& d = m.d[blockIdx.y];
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= d.C) return;
+  double s = 0.0;
+#pragma unroll 8
+  for (int b = 0; b < d.nbatch; ++b) s += d.rows[(size_t)b * d.C + i];
+  d.db[i] = (float)s;
+}
+
+extern "C" int sa_bias_multi(const SaBiasMulti* m, void* stream) {
+  if (!m || m->n <= 0 || m->n > SA_BIAS_MAX) return -22;
+  int maxC = 0, maxB = 0;
+  for (int j = 0; j < m->n; ++j) {
+    const SaBiasDesc& d = m->d[j];
+    if (!d.part || !d.rows || !d.db || d.nbatch <= 0 || d.nslab <= 0 || d.C <= 0 || d.ncomp < 1) return -22;
+    maxC = d.C > maxC ? d.C : maxC;
+    maxB = d.nbatch > maxB ? d.nbatch : maxB;
+  }
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  hipLaunchKernelGGL(sa_bias_multi_l1_kernel, dim3(sa_div_up(maxC, 32), maxB, m->n), dim3(32 * SA_SP_LANES), 0, st, *m);
+  hipLaunchKernelGGL(sa_bias_multi_l2_kernel, dim3(sa_div_up(maxC, 128), m->n), dim3(128), 0, st, *m);
+  hipError_t e = hipGetLastError();
+  return e == hipSuccess ? 0 : -(int)e;
+}
+
+// ---------------------------------------------------------------------------------
 // sa_reduce_finalize: slab reduction AND the finaliser that consumes it in ONE launch.
 //
 // The statistics of a convolution come out of its epilogue as per-tile partial slabs; until

@@ -446,6 +446,24 @@ def fin_norm_bwd(sums, lsums, groups, Cc, n, gamma, mean, rstd, sign=1.0, dgamma
     return o[0], o[1], o[2]
 
 
+def bias_multi(items):
+    """items: [(part [nbatch, nslab, C(, ncomp)] fp32 slabs, nbatch, C, ncomp, db fp32 [C])]: the bias gradients
+    of several layers in two launches (sa_bias_multi; same bits as sum_partials + fin_bias per layer)."""
+    lib = L.load()
+    dev = items[0][0].device
+    rows = torch.empty(sum(nb * cc for _, nb, cc, _, _ in items), dtype=torch.float64, device=dev)
+    rp, esz = rows.data_ptr(), 8
+    for i0 in range(0, len(items), L.BIAS_MAX):
+        m = L.SaBiasMulti()
+        chunk = items[i0:i0 + L.BIAS_MAX]
+        m.n = len(chunk)
+        for d, (part, nb, cc, ncomp, db) in zip(m.d, chunk):
+            d.part, d.rows, d.db = part.data_ptr(), rp, db.data_ptr()
+            d.nbatch, d.nslab, d.C, d.ncomp = nb, part.numel() // (nb * cc * ncomp), cc, ncomp
+            rp += nb * cc * esz
+        L.check(lib.sa_bias_multi(C.byref(m), L.stream()), "sa_bias_multi")
+
+
 def fin_bias(sums, B, Cc, db, ncomp=2):
     """db[c] = sum_b sums[b][c][0]; sums [B, Cc, ncomp] fp64."""
     L.check(L.load().sa_fin_bias(_f(sums), B, Cc, ncomp, _f(db), L.stream()), "sa_fin_bias")
