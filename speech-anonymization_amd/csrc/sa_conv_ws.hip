@@ -569,6 +569,7 @@ void sa_conv_ws_kernel(SaConvArgs a, int bcost, int total_tiles) {
   // iteration (t, it): MFMA loop of tile t from planes[it & 1]; in its filler slots the epilogue of
   // tile t-1 (from the copied accumulators), the transform of tile t+1 into planes[(it+1) & 1] and
   // the refill DMA of tile t+2.  One barrier per tile.
+  asm volatile("" : "=v"(accp[0]), "=v"(accp[1]));        // (read by the dummy epilogue of a range's first tile)
   for (int t = first, it = 0; t < last; ++t, ++it) {
     int lanem = lane_;
     asm volatile("" : "+v"(lanem));
@@ -594,7 +595,13 @@ void sa_conv_ws_kernel(SaConvArgs a, int bcost, int total_tiles) {
     // the slots hold the interior forms only; a tile at the end of an utterance (2 of 315 at the
     // training length) gets its masked transform / clamped DMA after the loop, a partial output tile
     // its bounds-checked epilogue in front of it, not overlapped
-    const bool slotE = doE && !partialE, slotT = !edgeT, slotD = !edgeT && !edgeD;
+    // (slotE does not ask for doE: in the first iteration of a range the epilogue slots run on the undefined
+    // accumulator copy with Tp = Tc and store into the rows and the statistics slab of THIS tile, which the next
+    // iteration's real epilogue overwrites -- same waves, same addresses, stores retire in order -- so the first
+    // tile is overlapped like the others)
+    // (not with pro_stats: that instance's register allocation tips into scratch with the first iteration in
+    // the overlapped body -- tools/ws_audit.py --, so its first tile stays plain)
+    const bool slotE = (PSTAT ? doE : true) && !partialE, slotT = !edgeT, slotD = !edgeT && !edgeD;
     if ((SWISH || PRO2) && Tn.b != cur_b) load_consts(Tn.b);
     xbase_d = row_ptr(a.x, Tnn.irow, WS_C * 4);
     if constexpr (PRO2) x2base_d = row_ptr(a.nb_x, Tnn.irow, WS_C * 4);

@@ -645,6 +645,7 @@ __device__ __forceinline__ void wsd_body(const SaConvArgs& a, int bcost, int tot
   bool cs_pending = false;
   bool ptr_step = false;                                   // the per-tile pointers can be advanced by their strides
   bool pend_issued = false;                                // the loads of the pending section (rows 32..63 of Tp) are in flight / in xr
+  asm volatile("" : "=v"(acc[1]));                         // (read by the dummy pending section of a range's first tile)
   for (int t = first, it = 0; t < last; ++t, ++it) {
     int lanem = lane_;
     asm volatile("" : "+v"(lanem));
@@ -664,7 +665,11 @@ __device__ __forceinline__ void wsd_body(const SaConvArgs& a, int bcost, int tot
     load_a(0);
     __builtin_amdgcn_sched_barrier(0);
     const bool doE = t > first;
-    const bool fast = doE && Tc.tile >= fast_lo && Tc.tile <= fast_hi;
+    // The first iteration of a range is overlapped too: there is no previous tile, so the slots of the
+    // pending section (rows 32..63 of tile t-1) run on an undefined accumulator with Tp = Tc -- they store
+    // into rows 32..63 and the statistics slab of THIS tile, which the next iteration's real pending
+    // section overwrites (same wave, same addresses, stores retire in order); its loads read this tile's rows.
+    const bool fast = Tc.tile >= fast_lo && Tc.tile <= fast_hi;
     const Tile Tnn = t + 2 < last ? next_tile(Tn) : Tn;       // (clamped: Tn is already the last tile then)
     const bool edgeT = is_edge(Tn), edgeD = is_edge(Tnn);   // (plain iterations only)
     WSD_STAMP(it, 9);
@@ -686,7 +691,7 @@ __device__ __forceinline__ void wsd_body(const SaConvArgs& a, int bcost, int tot
       yb_c = block8(a.y, Tc);
       xb_c = block8(a.ep_x, Tc);
       if constexpr (EP == 4) gb_c = block8(a.ep_g2, Tc);
-      stbase_p = const_cast<char*>(row_ptr(a.stats, t - 1, WS_C * 8));     // tile t-1 of the launch
+      stbase_p = const_cast<char*>(row_ptr(a.stats, __builtin_amdgcn_readfirstlane(t - (int)doE), WS_C * 8));     // tile t-1 of the launch (first iteration: see `fast`)
     }
     // (the strides hold from a fast iteration to the next fast one unless the tile after next was clamped)
     ptr_step = fast && t + 3 < last;
