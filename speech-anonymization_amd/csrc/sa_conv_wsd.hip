@@ -694,7 +694,7 @@ __device__ __forceinline__ void wsd_body(const SaConvArgs& a, int bcost, int tot
       stbase_p = const_cast<char*>(row_ptr(a.stats, __builtin_amdgcn_readfirstlane(t - (int)doE), WS_C * 8));     // tile t-1 of the launch (first iteration: see `fast`)
     }
     // (the strides hold from a fast iteration to the next fast one unless the tile after next was clamped)
-    ptr_step = fast && t + 3 < last;
+    ptr_step = fast && doE && t + 3 < last;                // (the first iteration's statistics pointer is the dummy's: recomputed next time)
     pl_cur = (it + 1) & 1 ? pl_off + WS_BUF_BYTES : pl_off;
     asm volatile("" : "+v"(pl_cur));
     WSD_STAMP(it, 10);
