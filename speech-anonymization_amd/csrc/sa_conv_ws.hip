@@ -122,7 +122,7 @@ void sa_conv_ws_kernel(SaConvArgs a, int bcost, int total_tiles) {
   // ends with its slowest workgroup.  An utterance counts ntiles + bcost.
   int first, last;
   {
-    const unsigned long long U = (unsigned long long)a.ntiles + (unsigned)bcost;
+    const unsigned long long U = (unsigned long long)a.ntiles + (unsigned)(bcost & 0xffff);
     const unsigned long long ctot = (unsigned long long)(total_tiles / a.ntiles) * U;
     auto inv = [&](unsigned long long c) {                  // first tile whose cumulative cost reaches c
       const unsigned long long k = c / U, r = c - k * U;
@@ -601,7 +601,7 @@ void sa_conv_ws_kernel(SaConvArgs a, int bcost, int total_tiles) {
     // tile is overlapped like the others)
     // (not with pro_stats: that instance's register allocation tips into scratch with the first iteration in
     // the overlapped body -- tools/ws_audit.py --, so its first tile stays plain)
-    const bool slotE = (PSTAT ? doE : true) && !partialE, slotT = !edgeT, slotD = !edgeT && !edgeD;
+    const bool slotE = (PSTAT || (bcost & 0x10000) ? doE : true) && !partialE, slotT = !edgeT, slotD = !edgeT && !edgeD;
     if ((SWISH || PRO2) && Tn.b != cur_b) load_consts(Tn.b);
     xbase_d = row_ptr(a.x, Tnn.irow, WS_C * 4);
     if constexpr (PRO2) x2base_d = row_ptr(a.nb_x, Tnn.irow, WS_C * 4);
@@ -858,7 +858,8 @@ int launch_ws(const SaConvArgs& a, hipStream_t st) {
 }  // namespace
 
 extern "C" int sa_conv_ws_set_bcost(int tiles) {
-  if (tiles < 0 || tiles > 64) return -22;
+  // (bit 16, timing A/B only: the first tile of every range takes the plain path, as before round 3's overlap of it)
+  if ((tiles & 0xffff) > 64 || (tiles & ~0x1ffff)) return -22;
   g_ws_bcost = tiles;
   return 0;
 }

@@ -174,7 +174,7 @@ __device__ __forceinline__ void wsd_body(const SaConvArgs& a, int bcost, int tot
   // cut at equal COST, an utterance counting ntiles + bcost.
   int first, last;
   {
-    const unsigned long long U = (unsigned long long)a.ntiles + (unsigned)bcost;
+    const unsigned long long U = (unsigned long long)a.ntiles + (unsigned)(bcost & 0xffff);
     const unsigned long long ctot = (unsigned long long)(total_tiles / a.ntiles) * U;
     auto inv = [&](unsigned long long c) {                  // first tile whose cumulative cost reaches c
       const unsigned long long k = c / U, r = c - k * U;
@@ -669,7 +669,7 @@ __device__ __forceinline__ void wsd_body(const SaConvArgs& a, int bcost, int tot
     // pending section (rows 32..63 of tile t-1) run on an undefined accumulator with Tp = Tc -- they store
     // into rows 32..63 and the statistics slab of THIS tile, which the next iteration's real pending
     // section overwrites (same wave, same addresses, stores retire in order); its loads read this tile's rows.
-    const bool fast = Tc.tile >= fast_lo && Tc.tile <= fast_hi;
+    const bool fast = (doE || !(bcost & 0x10000)) && Tc.tile >= fast_lo && Tc.tile <= fast_hi;
     const Tile Tnn = t + 2 < last ? next_tile(Tn) : Tn;       // (clamped: Tn is already the last tile then)
     const bool edgeT = is_edge(Tn), edgeD = is_edge(Tnn);   // (plain iterations only)
     WSD_STAMP(it, 9);
@@ -984,7 +984,8 @@ int wsd_variant(int dtype, int cin, int cout, int sa, int u, const SaConvArgs* a
 }  // namespace
 
 extern "C" int sa_conv_wsd_set_bcost(int tiles) {
-  if (tiles < 0 || tiles > 64) return -22;
+  // (bit 16, timing A/B only: the first tile of every range takes the plain path, as before round 3's overlap of it)
+  if ((tiles & 0xffff) > 64 || (tiles & ~0x1ffff)) return -22;
   g_wsd_bcost = tiles;
   return 0;
 }
