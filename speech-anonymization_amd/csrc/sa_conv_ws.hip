@@ -134,6 +134,35 @@ void sa_conv_ws_kernel(SaConvArgs a, int bcost, int total_tiles) {
   }
   if (first >= last) return;
 
+  // ---- the weights: this wave's 32 output columns, all taps / channels, hi and lo images ----
+  bf16x8 Bh[WS_NTAPS][WS_KSTEPS], Bl[WS_NTAPS][WS_KSTEPS];
+  {
+    const bf16x8* wp = reinterpret_cast<const bf16x8*>(a.wp);
+#pragma unroll
+    for (int t = 0; t < WS_NTAPS; ++t) {
+      const bool has_t = UU == 1 || t < ntap_;
+      const bf16x8* wt = wp + ((size_t)a.taps.widx[ph_][has_t ? t : 0] * WS_KSTEPS * NWN + wn_) * 64 + lane_;
+#pragma unroll
+      for (int k = 0; k < WS_KSTEPS; ++k) {
+        Bh[t][k] = wt[(size_t)k * NWN * 64];
+        Bl[t][k] = wt[(size_t)a.wlo_off + (size_t)k * NWN * 64];
+        if (UU == 2 && !has_t) {                           // the phase with fewer taps: zero fragments
+          Bh[t][k] = bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
+          Bl[t][k] = bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
+        }
+      }
+      // one tap at a time, moved to its AGPR home before the next tap is fetched (all 80 loads at
+      // once would need 320 VGPRs).  The empty asm also makes hipcc wait for the loads HERE: a value
+      // still "pending" at the loop header gets its s_waitcnt vmcnt(0) inside the loop, in front of
+      // every use, and that wait would drain the LDS-DMA in flight there.
+#pragma unroll
+      for (int k = 0; k < WS_KSTEPS; ++k) {
+        if (t * WS_KSTEPS + k < WS_NAGPR_FRAGS) asm volatile("" : "+a"(Bh[t][k]), "+a"(Bl[t][k]));
+        else asm volatile("" : "+v"(Bh[t][k]), "+v"(Bl[t][k]));
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }
   float bv = a.bias ? a.bias[wn_ * 32 + (lane_ & 31)] : 0.0f;
   float relu_floor = a.relu ? 0.0f : -__builtin_inff();     // max(v, -inf) = v: no branch in the slot
   const bool has_stats = a.stats != nullptr, has_ao = a.a_out != nullptr;
@@ -508,46 +537,14 @@ void sa_conv_ws_kernel(SaConvArgs a, int bcost, int total_tiles) {
   Tile Tc = tile_of(first), Tn = tile_of(first + 1 < last ? first + 1 : last - 1), Tp = Tc;
 #pragma unroll
   for (int q = 0; q < 4; ++q) { csum[q] = 0.0f; csq[q] = 0.0f; }
-  const bool ec = is_edge(Tc), en = is_edge(Tn);
   {
+    const bool ec = is_edge(Tc), en = is_edge(Tn);
     xbase_d = row_ptr(a.x, Tc.irow, WS_C * 4);
     if constexpr (PRO2) x2base_d = row_ptr(a.nb_x, Tc.irow, WS_C * 4);
     aobase_t = const_cast<char*>(row_ptr(a.a_out, Tc.irow, WS_C * 2));
     pl_cur = pl_off;
 #pragma unroll
     for (int j = 0; j < WS_DPW; ++j) dma_piece(Tc, ec, j);
-  }
-  // (the first tile's rows are on their way into LDS while the weights are fetched: the DMA needs no register)
-  // ---- the weights: this wave's 32 output columns, all taps / channels, hi and lo images ----
-  bf16x8 Bh[WS_NTAPS][WS_KSTEPS], Bl[WS_NTAPS][WS_KSTEPS];
-  {
-    const bf16x8* wp = reinterpret_cast<const bf16x8*>(a.wp);
-#pragma unroll
-    for (int t = 0; t < WS_NTAPS; ++t) {
-      const bool has_t = UU == 1 || t < ntap_;
-      const bf16x8* wt = wp + ((size_t)a.taps.widx[ph_][has_t ? t : 0] * WS_KSTEPS * NWN + wn_) * 64 + lane_;
-#pragma unroll
-      for (int k = 0; k < WS_KSTEPS; ++k) {
-        Bh[t][k] = wt[(size_t)k * NWN * 64];
-        Bl[t][k] = wt[(size_t)a.wlo_off + (size_t)k * NWN * 64];
-        if (UU == 2 && !has_t) {                           // the phase with fewer taps: zero fragments
-          Bh[t][k] = bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
-          Bl[t][k] = bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
-        }
-      }
-      // one tap at a time, moved to its AGPR home before the next tap is fetched (all 80 loads at
-      // once would need 320 VGPRs).  The empty asm also makes hipcc wait for the loads HERE: a value
-      // still "pending" at the loop header gets its s_waitcnt vmcnt(0) inside the loop, in front of
-      // every use, and that wait would drain the LDS-DMA in flight there.
-#pragma unroll
-      for (int k = 0; k < WS_KSTEPS; ++k) {
-        if (t * WS_KSTEPS + k < WS_NAGPR_FRAGS) asm volatile("" : "+a"(Bh[t][k]), "+a"(Bl[t][k]));
-        else asm volatile("" : "+v"(Bh[t][k]), "+v"(Bl[t][k]));
-      }
-      __builtin_amdgcn_sched_barrier(0);
-    }
-  }
-  {
     xbase_d = row_ptr(a.x, Tn.irow, WS_C * 4);
     if constexpr (PRO2) x2base_d = row_ptr(a.nb_x, Tn.irow, WS_C * 4);
     if (SWISH || PRO2) load_consts(Tc.b);

@@ -186,6 +186,43 @@ __device__ __forceinline__ void wsd_body(const SaConvArgs& a, int bcost, int tot
   }
   if (first >= last) return;
 
+  // ---- the weights: this wave's 32 output columns, all taps / channels, hi and lo images ----
+  bf16x8 Bh[WS_NTAPS][WS_KSTEPS], Bl[WS_NTAPS][WS_KSTEPS];
+  {
+    const bf16x8* wp = reinterpret_cast<const bf16x8*>(a.wp);
+#pragma unroll
+    for (int t = 0; t < WS_NTAPS; ++t) {
+      const bf16x8* wt = wp + ((size_t)a.taps.widx[0][t] * WS_KSTEPS * 4 + wave_) * 64 + lane_;
+#pragma unroll
+      for (int k = 0; k < WS_KSTEPS; ++k) {
+        Bh[t][k] = wt[(size_t)k * 4 * 64];
+        Bl[t][k] = wt[(size_t)a.wlo_off + (size_t)k * 4 * 64];
+      }
+      // one tap at a time, moved to its home before the next tap is fetched; the empty asm also makes
+      // hipcc wait for the loads HERE and not in front of their first use inside the tile loop
+#pragma unroll
+      for (int k = 0; k < WS_KSTEPS; ++k) {
+        const int pr = t * WS_KSTEPS + k;
+        if (pr < WS_NAGPR_FRAGS) {
+          asm volatile("" : "+a"(Bh[t][k]), "+a"(Bl[t][k]));
+        } else if (pr < WS_NAGPR_FRAGS + WS_NHAND) {
+          typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+          const u32x4 uh = __builtin_bit_cast(u32x4, Bh[t][k]), ul = __builtin_bit_cast(u32x4, Bl[t][k]);
+          if (pr == 30)
+            asm volatile("v_accvgpr_write_b32 a240, %0\n\tv_accvgpr_write_b32 a241, %1\n\tv_accvgpr_write_b32 a242, %2\n\tv_accvgpr_write_b32 a243, %3\n\t"
+                         "v_accvgpr_write_b32 a244, %4\n\tv_accvgpr_write_b32 a245, %5\n\tv_accvgpr_write_b32 a246, %6\n\tv_accvgpr_write_b32 a247, %7"
+                         :: "v"(uh[0]), "v"(uh[1]), "v"(uh[2]), "v"(uh[3]), "v"(ul[0]), "v"(ul[1]), "v"(ul[2]), "v"(ul[3]));
+          else
+            asm volatile("v_accvgpr_write_b32 a248, %0\n\tv_accvgpr_write_b32 a249, %1\n\tv_accvgpr_write_b32 a250, %2\n\tv_accvgpr_write_b32 a251, %3\n\t"
+                         "v_accvgpr_write_b32 a252, %4\n\tv_accvgpr_write_b32 a253, %5\n\tv_accvgpr_write_b32 a254, %6\n\tv_accvgpr_write_b32 a255, %7"
+                         :: "v"(uh[0]), "v"(uh[1]), "v"(uh[2]), "v"(uh[3]), "v"(ul[0]), "v"(ul[1]), "v"(ul[2]), "v"(ul[3]));
+        } else {
+          asm volatile("" : "+v"(Bh[t][k]), "+v"(Bl[t][k]));
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }
   // (data gradients carry no bias: wsd_variant() sends a launch with one to the one-tile kernel)
   constexpr bool MASK = PRO2 && EP != 1;                    // ReLU mask of the BatchNorm blocks' prologue (wsd_variant() checks)
   const bool has_stats = a.stats != nullptr, has_ao = a.a_out != nullptr;
@@ -571,54 +608,14 @@ __device__ __forceinline__ void wsd_body(const SaConvArgs& a, int bcost, int tot
   Tile Tc = tile_of(first), Tn = tile_of(first + 1 < last ? first + 1 : last - 1), Tp = Tc;
 #pragma unroll
   for (int q = 0; q < 4; ++q) csum[q] = 0.0f;
-  const bool ec = is_edge(Tc), en = is_edge(Tn);
   {
+    const bool ec = is_edge(Tc), en = is_edge(Tn);
     xbase_d = row_ptr(a.x, Tc.irow, WS_C * 4);
     if constexpr (PRO2) x2base_d = row_ptr(a.nb_x, Tc.irow, WS_C * 4);
     aobase_t = const_cast<char*>(row_ptr(a.a_out, Tc.irow, WS_C * 2));
     pl_cur = pl_off;
 #pragma unroll
     for (int j = 0; j < WS_DPW; ++j) dma_piece(Tc, ec, j);
-  }
-  // (the first tile's rows are on their way into LDS while the weights are fetched: the DMA needs no register)
-  // ---- the weights: this wave's 32 output columns, all taps / channels, hi and lo images ----
-  bf16x8 Bh[WS_NTAPS][WS_KSTEPS], Bl[WS_NTAPS][WS_KSTEPS];
-  {
-    const bf16x8* wp = reinterpret_cast<const bf16x8*>(a.wp);
-#pragma unroll
-    for (int t = 0; t < WS_NTAPS; ++t) {
-      const bf16x8* wt = wp + ((size_t)a.taps.widx[0][t] * WS_KSTEPS * 4 + wave_) * 64 + lane_;
-#pragma unroll
-      for (int k = 0; k < WS_KSTEPS; ++k) {
-        Bh[t][k] = wt[(size_t)k * 4 * 64];
-        Bl[t][k] = wt[(size_t)a.wlo_off + (size_t)k * 4 * 64];
-      }
-      // one tap at a time, moved to its home before the next tap is fetched; the empty asm also makes
-      // hipcc wait for the loads HERE and not in front of their first use inside the tile loop
-#pragma unroll
-      for (int k = 0; k < WS_KSTEPS; ++k) {
-        const int pr = t * WS_KSTEPS + k;
-        if (pr < WS_NAGPR_FRAGS) {
-          asm volatile("" : "+a"(Bh[t][k]), "+a"(Bl[t][k]));
-        } else if (pr < WS_NAGPR_FRAGS + WS_NHAND) {
-          typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-          const u32x4 uh = __builtin_bit_cast(u32x4, Bh[t][k]), ul = __builtin_bit_cast(u32x4, Bl[t][k]);
-          if (pr == 30)
-            asm volatile("v_accvgpr_write_b32 a240, %0\n\tv_accvgpr_write_b32 a241, %1\n\tv_accvgpr_write_b32 a242, %2\n\tv_accvgpr_write_b32 a243, %3\n\t"
-                         "v_accvgpr_write_b32 a244, %4\n\tv_accvgpr_write_b32 a245, %5\n\tv_accvgpr_write_b32 a246, %6\n\tv_accvgpr_write_b32 a247, %7"
-                         :: "v"(uh[0]), "v"(uh[1]), "v"(uh[2]), "v"(uh[3]), "v"(ul[0]), "v"(ul[1]), "v"(ul[2]), "v"(ul[3]));
-          else
-            asm volatile("v_accvgpr_write_b32 a248, %0\n\tv_accvgpr_write_b32 a249, %1\n\tv_accvgpr_write_b32 a250, %2\n\tv_accvgpr_write_b32 a251, %3\n\t"
-                         "v_accvgpr_write_b32 a252, %4\n\tv_accvgpr_write_b32 a253, %5\n\tv_accvgpr_write_b32 a254, %6\n\tv_accvgpr_write_b32 a255, %7"
-                         :: "v"(uh[0]), "v"(uh[1]), "v"(uh[2]), "v"(uh[3]), "v"(ul[0]), "v"(ul[1]), "v"(ul[2]), "v"(ul[3]));
-        } else {
-          asm volatile("" : "+v"(Bh[t][k]), "+v"(Bl[t][k]));
-        }
-      }
-      __builtin_amdgcn_sched_barrier(0);
-    }
-  }
-  {
     xbase_d = row_ptr(a.x, Tn.irow, WS_C * 4);
     if constexpr (PRO2) x2base_d = row_ptr(a.nb_x, Tn.irow, WS_C * 4);
     load_consts(Tc.b);
