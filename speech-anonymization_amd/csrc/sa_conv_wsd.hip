@@ -185,6 +185,7 @@ __device__ __forceinline__ void wsd_body(const SaConvArgs& a, int bcost, int tot
     last = blockIdx.x + 1 == gridDim.x ? total_tiles : inv(ctot * (blockIdx.x + 1) / gridDim.x);
   }
   if (first >= last) return;
+  WSD_STAMP(63, 0); WSD_STAMP_RT(63, 8);
 
   // ---- the weights: this wave's 32 output columns, all taps / channels, hi and lo images ----
   bf16x8 Bh[WS_NTAPS][WS_KSTEPS], Bl[WS_NTAPS][WS_KSTEPS];
@@ -223,6 +224,7 @@ __device__ __forceinline__ void wsd_body(const SaConvArgs& a, int bcost, int tot
       __builtin_amdgcn_sched_barrier(0);
     }
   }
+  WSD_STAMP(63, 1);
   // (data gradients carry no bias: wsd_variant() sends a launch with one to the one-tile kernel)
   constexpr bool MASK = PRO2 && EP != 1;                    // ReLU mask of the BatchNorm blocks' prologue (wsd_variant() checks)
   const bool has_stats = a.stats != nullptr, has_ao = a.a_out != nullptr;
@@ -641,6 +643,7 @@ __device__ __forceinline__ void wsd_body(const SaConvArgs& a, int bcost, int tot
   // rows 32..63 of tile t-1 (acc[1]), the loads for the epilogue of rows 0..31 of tile t, the transform
   // of pieces 0..NP0-1 of tile t+1; section 1 = rows 32..63 -> acc[1], epilogue of rows 0..31 of tile t,
   // loads for rows 32..63, pieces NP0.. of tile t+1.  One barrier per tile.
+  WSD_STAMP(63, 2);
   yb_c = block8(a.y, Tc);
   bool cs_pending = false;
   bool ptr_step = false;                                   // the per-tile pointers can be advanced by their strides
@@ -882,6 +885,7 @@ __device__ __forceinline__ void wsd_body(const SaConvArgs& a, int bcost, int tot
     epi_plain(std::integral_constant<int, 1>{}, Tp, block8(a.y, Tp), block8(a.ep_x, Tp), EP == 4 ? block8(a.ep_g2, Tp) : nullptr);
     epi_stats();
   }
+  WSD_STAMP(63, 3); WSD_STAMP_RT(63, 9);
 #undef WS_IDS
 #undef WSD_IMM
 #undef WSD_Q

@@ -69,6 +69,11 @@ for cname in (sys.argv[1:] or ["enc11", "tdnn3"]):
     lib.sa_wsd_dbg_read(buf)
     st = [[buf[i * 16 + j] for j in range(16)] for i in range(64)]
     print(f"== {cname}: {e0.elapsed_time(e1) / 10 * 1e3:.1f} us per launch (stamped build)")
+    pro = st[63]
+    st[63] = [0] * 16
+    if pro[0]:
+        print(f"   workgroup 7: entry -> weights in registers {pro[1] - pro[0]} cycles, -> first tile staged {pro[2] - pro[1]}, "
+              f"tile walk + tail {pro[3] - pro[2]}; entry..exit {(pro[9] - pro[8]) * 0.01:.1f} us of the launch's time")
     n = max(i for i in range(64) if st[i][0]) + 1
     rt0, rtn = st[0][5], st[n - 1][5]
     cyc = st[n - 1][0] - st[0][0]
