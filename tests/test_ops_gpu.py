@@ -1319,3 +1319,27 @@ def test_colsums_writes_fp32_gradient_views():
     torch.testing.assert_close(s[:, 1], ref1, rtol=1e-5, atol=1e-5)
     s2 = ops.colsums(X)                                   # no outputs: sums only (sum, sum of squares)
     torch.testing.assert_close(s2[:, 1], (X.double() ** 2).sum(0), rtol=1e-6, atol=1e-6)
+
+
+def test_batched_bias_gradients_equal_the_per_layer_launches():
+    """sa_bias_multi (the bias gradients of a backward stage in two launches) against sa_sum_partials +
+    sa_fin_bias per layer: same lanes, same order -> the same BITS; more records than one launch pair takes
+    (SA_BIAS_MAX = 8), mixed slab layouts ([.., C, 2] statistics slabs and [.., C] column sums), ragged sizes."""
+    torch.manual_seed(11)
+    d = torch.device("cuda:0")
+    shapes = [(32, 315, 128, 2), (32, 315, 128, 1), (10, 630, 64, 2), (3, 1260, 32, 1), (1, 7, 64, 2), (6, 17, 128, 1),
+              (32, 315, 64, 1), (4, 40, 32, 2), (5, 9, 128, 2), (2, 3, 64, 1)]
+    items, ref = [], []
+    for nb, ns, cc, ncomp in shapes:
+        part = torch.randn(nb, ns, cc, ncomp, device=d) * (1.0 + torch.rand(1, device=d) * 100)
+        db = torch.full((cc,), float("nan"), device=d)
+        items.append((part, nb, cc, ncomp, db))
+        r = torch.empty(cc, device=d)
+        ops.fin_bias(ops.sum_partials(part, nb, n=cc * ncomp), nb, cc, r, ncomp=ncomp)
+        ref.append(r)
+    ops.bias_multi(items)
+    torch.cuda.synchronize()
+    for (part, nb, cc, ncomp, db), r in zip(items, ref):
+        assert torch.equal(db, r), (nb, cc, ncomp)
+        exact = part[..., 0].double().sum(dim=(0, 1))
+        assert float((db.double() - exact).abs().max()) <= 1e-6 * float(exact.abs().max() + 1.0)
