@@ -1325,8 +1325,9 @@ def test_batched_bias_gradients_equal_the_per_layer_launches():
     """sa_bias_multi (the bias gradients of a backward stage in two launches) against sa_sum_partials +
     sa_fin_bias per layer: same lanes, same order -> the same BITS; more records than one launch pair takes
     (SA_BIAS_MAX = 8), mixed slab layouts ([.., C, 2] statistics slabs and [.., C] column sums), ragged sizes."""
+    from speech_anonymization_amd import ops
     torch.manual_seed(11)
-    d = torch.device("cuda:0")
+    d = dev()
     shapes = [(32, 315, 128, 2), (32, 315, 128, 1), (10, 630, 64, 2), (3, 1260, 32, 1), (1, 7, 64, 2), (6, 17, 128, 1),
               (32, 315, 64, 1), (4, 40, 32, 2), (5, 9, 128, 2), (2, 3, 64, 1)]
     items, ref = [], []
