@@ -241,7 +241,6 @@ def conv_gemm(x, wp, bias, cin, cout, sa, u, phases, Lout, s1=None, t1=None, s2=
         route = lib.sa_conv_gemm_route(kc, cin, cout, sa, u, C.byref(a))
         tname = {L.F32: "float", L.BF16: "bf16_t", L.BF16X3: "bf16x3_t", L.BF16X1F: "bf16x1f_t", L.FP8: "fp8_t"}[kc]
         ws_mode = (5 if s2 is not None else 0) if s1 is None else 3 if want_pro_stats else 4 if s2 is not None else 1
-        offs = [o for ph in phases for o, _ in ph]
         # (the five instances <taps, span, prologue, epilogue> of the fused data-gradient kernel are ONE
         # kernel for the roofline record: same source, same structure, 1 launch per step each)
         kind = (f"sa_conv_wsd_kernel ({tname}, {cin}->{cout}; 5 instances)" if route == 3 else
