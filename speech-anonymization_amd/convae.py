@@ -118,6 +118,8 @@ class ConvAutoencoder(nn.Module):
         # within the run-to-run spread), so the separate sa_sum_partials / sa_fin_* launches stay
         # the default (they are also what runs wherever the sums are all-reduced first).
         self.fused_finalize = os.environ.get("SA_FUSED_FINALIZE", "0") == "1"
+        # the InstanceNorm FORWARD pairs alone (per utterance: no hand-off between workgroups in that mode)
+        self.fused_in_fwd = os.environ.get("SA_FUSED_IN_FWD", "0") == "1"
         # The FC head of the classifier is ~12 (forward) / ~25 (backward) launches of 5-10 us each
         # that nothing else waits for until the branches merge: True runs them on a side stream
         # beside the decoder's convolutions (forward: after the pooling; backward: the decoder's
@@ -360,7 +362,7 @@ class _ConvAEFn(torch.autograd.Function):
         ff = model.fused_finalize
 
         def inorm(stats, n, prefix, C):
-            if ff:
+            if ff or model.fused_in_fwd:
                 return ops.reduce_finalize(L.FIN_IN_FWD, stats, B, C, count=n, gamma=P[prefix + ".weight"],
                                            beta=P[prefix + ".bias"])
             sums = ops.sum_partials(stats, B)
