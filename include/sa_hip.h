@@ -390,6 +390,16 @@ int sa_ln_leaky_fwd(const void* x, const void* gamma, const void* beta, void* y,
                     float eps, float slope, void* stream);
 int sa_ln_leaky_bwd(const void* dy, const void* x, const float* stat, const void* gamma, const void* beta, void* dx,
                     int rows, int d, float slope, void* stream);
+/* sa_asr_block0_fwd / _bwd: block 0 of the front end -- Conv2d(1 -> C = 128, 3 x 3, stride 2, reflect "same"
+ *   padding) + LayerNorm over (F' = 40, C) + LeakyReLU on x [B][T][F = 80] -> y [B][ceil(T/2)][40][128] -- as one
+ *   pass each way (-ENOSYS for other F / C).  w [C][3][3], bias [C], gamma / beta [40][128], all bf16.
+ *   stat [B * ceil(T/2)][2] (mean, rstd; NULL under no_grad) is all the backward keeps besides x: it recomputes
+ *   the convolution.  part: fp32 scratch [B * ceil(T/2)][3][F + 2]; dx [B][T][F] bf16. */
+int sa_asr_block0_fwd(const void* x, const void* w, const void* bias, const void* gamma, const void* beta, void* y,
+                      float* stat, int B, int T, int F, int C, float eps, float slope, void* stream);
+int sa_asr_block0_bwd(const void* dy, const void* x, const void* w, const void* bias, const void* gamma,
+                      const void* beta, const float* stat, float* part, void* dx, int B, int T, int F, int C,
+                      float slope, void* stream);
 int sa_reflect_pad_fwd(const void* x, void* y, int B, int T, int F, int C, void* stream);
 int sa_reflect_pad_bwd(const void* dy, void* dx, int B, int T, int F, int C, void* stream);
 

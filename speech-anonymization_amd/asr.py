@@ -112,8 +112,16 @@ class ConvolutionFrontEnd(torch.nn.Module):
     def forward(self, x):
         """activations stay [B, T, F, C] in memory (channels-last: what MIOpen's NHWC implicit-GEMM
         kernels take); the convolution sees the logical NCHW view of the same bytes"""
-        x = x.unsqueeze(-1)                                       # [B, T, F, 1]
+        first = 0
+        if (_hip(x) and x.shape[-1] == 80 and x.shape[1] >= 3 and self.w[0].shape == (128, 1, 3, 3)
+                and self.strides[0] == 2 and self.w[0].dtype == x.dtype):
+            x = _Block0.apply(x, self.w[0], self.b[0], self.ln_w[0], self.ln_b[0], 1e-5, 0.01)
+            first = 1
+        else:
+            x = x.unsqueeze(-1)                                   # [B, T, F, 1]
         for i, (k, s) in enumerate(zip(self.kernel_sizes, self.strides)):
+            if i < first:
+                continue
             if k > 1:
                 x = _reflect_pad1(x)
             w = self.w[i].to(x.dtype)
@@ -151,6 +159,28 @@ class _LNLeaky(torch.autograd.Function):
         from . import ops
         x, stat, gamma, beta = ctx.saved_tensors
         return ops.ln_leaky_bwd(dy.contiguous(), x, stat, gamma, beta, ctx.slope), None, None, None, None
+
+
+class _Block0(torch.autograd.Function):
+    """block 0 of the front end (Conv2d 1 -> 128, 3 x 3, stride 2, reflect padding + LayerNorm + LeakyReLU)
+    as one pass each way (sa_asr_block0_fwd / _bwd): nine multiply-adds per output, bound by its output"""
+
+    @staticmethod
+    def forward(ctx, x, w, b, gamma, beta, eps, slope):
+        from . import ops
+        x = x.contiguous()
+        save = ctx.needs_input_grad[0]
+        y, stat = ops.asr_block0(x, w, b, gamma, beta, eps, slope, save)
+        if save:
+            ctx.save_for_backward(x, w, b, gamma, beta, stat)
+        ctx.slope = slope
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        from . import ops
+        x, w, b, gamma, beta, stat = ctx.saved_tensors
+        return (ops.asr_block0_bwd(dy.contiguous(), x, w, b, gamma, beta, stat, ctx.slope),) + (None,) * 6
 
 
 def _sdpa_mask(bias, B, h, Tq, Tk, dtype):

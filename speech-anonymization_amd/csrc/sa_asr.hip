@@ -397,3 +397,246 @@ extern "C" int sa_ln_leaky_bwd(const void* dy, const void* x, const float* stat,
   hipError_t e = hipGetLastError();
   return e == hipSuccess ? 0 : -(int)e;
 }
+
+// ---------------------------------------------------------------------------------------------------
+// Block 0 of the convolutional front end as ONE pass each way: Conv2d(1 -> 128, 3 x 3, stride 2, reflect
+// "same" padding) -> LayerNorm over (frequency, channel) -> LeakyReLU on [B][T][F] features
+// (speechbrain_configs/convae.yaml:139-146; F = 80 -> F' = 40, 40 x 128 = 5120 outputs per output row).
+// The convolution is 9 multiply-adds per output: the block is bound by its 165 MB of bf16 output, which the
+// library path wrote (and re-read) four times (convolution 0.5 ms, layout copy, LayerNorm, LeakyReLU).
+// One 256-thread workgroup per output row (b, i): thread t owns channels [4 (t % 32), +4) of the columns
+// j = 8 k + t / 32 (k = 0..4), i.e. elements [1024 k + 4 t, +4) of the row -- the layout of ln_leaky above.
+//   forward : the three padded input rows in LDS, z in registers, row statistics, y stored once
+//   backward: z recomputed from the input (nothing but the statistics is kept), LayerNorm / LeakyReLU
+//             backward, then the input gradient in two deterministic steps: per output row the sums over the
+//             128 channels per tap -> a [3][F + 2] gradient of its padded input rows (part), and a gather
+//             kernel that folds the overlap of neighbouring rows and the reflection into d x.
+// ---------------------------------------------------------------------------------------------------
+#define SA_B0_F 80
+#define SA_B0_FO 40
+#define SA_B0_C 128
+#define SA_B0_D (SA_B0_FO * SA_B0_C)
+
+__device__ inline void b0_stage_rows(const bf16_t* __restrict__ x, int b, int i, int T, float (*xp)[SA_B0_F + 2]) {
+  // padded rows 2i .. 2i+2 = input rows reflect(2i - 1 + kh), padded columns q = reflect(q - 1)
+  for (int e = threadIdx.x; e < 3 * (SA_B0_F + 2); e += 256) {
+    const int kh = e / (SA_B0_F + 2), q = e % (SA_B0_F + 2);
+    const int t = reflect1(2 * i - 1 + kh, T), f = reflect1(q - 1, SA_B0_F);
+    xp[kh][q] = (float)x[((size_t)b * T + t) * SA_B0_F + f];
+  }
+}
+
+__device__ inline void b0_conv(const float (*xp)[SA_B0_F + 2], const float (*wr)[9], const float* br, float (*z)[4]) {
+  const int jb = threadIdx.x >> 5;
+#pragma unroll
+  for (int k = 0; k < 5; ++k) {
+    const int j = 8 * k + jb;
+    float v[9];
+#pragma unroll
+    for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+      for (int kw = 0; kw < 3; ++kw) v[3 * kh + kw] = xp[kh][2 * j + kw];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      float s = br[c];
+#pragma unroll
+      for (int u = 0; u < 9; ++u) s = fmaf(wr[c][u], v[u], s);
+      z[k][c] = s;
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void asr_block0_fwd_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ w,
+                                                             const bf16_t* __restrict__ bias,
+                                                             const bf16_t* __restrict__ gamma,
+                                                             const bf16_t* __restrict__ beta, bf16_t* __restrict__ y,
+                                                             float* __restrict__ stat, int T, int To, float eps,
+                                                             float slope) {
+  __shared__ float xp[3][SA_B0_F + 2];
+  __shared__ float red[4];
+  const int row = blockIdx.x, b = row / To, i = row % To;
+  const int c0 = 4 * (threadIdx.x & 31);
+  float wr[4][9], br[4];
+#pragma unroll
+  for (int c = 0; c < 4; ++c) {
+    br[c] = (float)bias[c0 + c];
+#pragma unroll
+    for (int u = 0; u < 9; ++u) wr[c][u] = (float)w[(c0 + c) * 9 + u];
+  }
+  b0_stage_rows(x, b, i, T, xp);
+  __syncthreads();
+  float z[5][4];
+  b0_conv(xp, wr, br, z);
+  // the convolution's output is a bf16 tensor in the unfused graph: round it, so that the normalisation sees
+  // the values the library path would have stored
+  float sum = 0.f;
+#pragma unroll
+  for (int k = 0; k < 5; ++k) {
+    unpack4(pack4(z[k]), z[k]);
+    sum += (z[k][0] + z[k][1]) + (z[k][2] + z[k][3]);
+  }
+  const float mean = block_sum(sum, red) * (1.0f / SA_B0_D);
+  float sq = 0.f;
+#pragma unroll
+  for (int k = 0; k < 5; ++k)
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      z[k][c] -= mean;
+      sq = fmaf(z[k][c], z[k][c], sq);
+    }
+  const float rstd = rsqrtf(block_sum(sq, red) * (1.0f / SA_B0_D) + eps);
+  if (stat && threadIdx.x == 0) {
+    stat[2 * row] = mean;
+    stat[2 * row + 1] = rstd;
+  }
+  const size_t base = (size_t)row * SA_B0_D + threadIdx.x * 4;
+#pragma unroll
+  for (int k = 0; k < 5; ++k) {
+    float g[4], bt[4], o[4];
+    unpack4(*reinterpret_cast<const uint2*>(gamma + threadIdx.x * 4 + 1024 * k), g);
+    unpack4(*reinterpret_cast<const uint2*>(beta + threadIdx.x * 4 + 1024 * k), bt);
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      const float v = fmaf(z[k][c] * rstd, g[c], bt[c]);
+      o[c] = v > 0.f ? v : v * slope;
+    }
+    *reinterpret_cast<uint2*>(y + base + 1024 * k) = pack4(o);
+  }
+}
+
+// part[row][kh][q]: gradient of padded input row 2i + kh, padded column q, from output row `row` alone
+__global__ __launch_bounds__(256) void asr_block0_bwd_kernel(const bf16_t* __restrict__ dy, const bf16_t* __restrict__ x,
+                                                             const bf16_t* __restrict__ w,
+                                                             const bf16_t* __restrict__ bias,
+                                                             const bf16_t* __restrict__ gamma,
+                                                             const bf16_t* __restrict__ beta,
+                                                             const float* __restrict__ stat, float* __restrict__ part,
+                                                             int T, int To, float slope) {
+  __shared__ float xp[3][SA_B0_F + 2];
+  __shared__ float red[4];
+  __shared__ float s9[SA_B0_FO][9];
+  const int row = blockIdx.x, b = row / To, i = row % To;
+  const int c0 = 4 * (threadIdx.x & 31), jb = threadIdx.x >> 5;
+  float wr[4][9], br[4];
+#pragma unroll
+  for (int c = 0; c < 4; ++c) {
+    br[c] = (float)bias[c0 + c];
+#pragma unroll
+    for (int u = 0; u < 9; ++u) wr[c][u] = (float)w[(c0 + c) * 9 + u];
+  }
+  b0_stage_rows(x, b, i, T, xp);
+  __syncthreads();
+  float z[5][4], g[5][4];
+  b0_conv(xp, wr, br, z);
+  const float mean = stat[2 * row], rstd = stat[2 * row + 1];
+  const size_t base = (size_t)row * SA_B0_D + threadIdx.x * 4;
+  float sg = 0.f, sgx = 0.f;
+#pragma unroll
+  for (int k = 0; k < 5; ++k) {
+    float gm[4], bt[4];
+    unpack4(pack4(z[k]), z[k]);                                     // (the forward's rounding)
+    unpack4(*reinterpret_cast<const uint2*>(dy + base + 1024 * k), g[k]);
+    unpack4(*reinterpret_cast<const uint2*>(gamma + threadIdx.x * 4 + 1024 * k), gm);
+    unpack4(*reinterpret_cast<const uint2*>(beta + threadIdx.x * 4 + 1024 * k), bt);
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      z[k][c] = (z[k][c] - mean) * rstd;                             // xhat
+      const float v = fmaf(z[k][c], gm[c], bt[c]);
+      g[k][c] *= (v > 0.f ? 1.0f : slope) * gm[c];
+      sg += g[k][c];
+      sgx = fmaf(g[k][c], z[k][c], sgx);
+    }
+  }
+  const float mg = block_sum(sg, red) * (1.0f / SA_B0_D), mgx = block_sum(sgx, red) * (1.0f / SA_B0_D);
+  // d z, then per column j and tap the sum over the 128 channels: 4 in the thread, 32 lanes by butterfly
+#pragma unroll
+  for (int k = 0; k < 5; ++k) {
+    float t9[9];
+#pragma unroll
+    for (int u = 0; u < 9; ++u) t9[u] = 0.f;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      // the unfused graph holds d z as a bf16 tensor between the LayerNorm backward and the convolution's
+      const float dz = (float)(bf16_t)(rstd * (g[k][c] - mg - z[k][c] * mgx));
+#pragma unroll
+      for (int u = 0; u < 9; ++u) t9[u] = fmaf(dz, wr[c][u], t9[u]);
+    }
+#pragma unroll
+    for (int u = 0; u < 9; ++u) {
+#pragma unroll
+      for (int o = 16; o > 0; o >>= 1) t9[u] += __shfl_xor(t9[u], o, 64);       // within the 32 lanes of a column
+    }
+    if ((threadIdx.x & 31) == 0) {
+#pragma unroll
+      for (int u = 0; u < 9; ++u) s9[8 * k + jb][u] = t9[u];
+    }
+  }
+  __syncthreads();
+  // padded column q of padded row kh collects (j, kw) with 2 j + kw = q: at most two terms, in j order
+  for (int e = threadIdx.x; e < 3 * (SA_B0_F + 2); e += 256) {
+    const int kh = e / (SA_B0_F + 2), q = e % (SA_B0_F + 2);
+    float s = 0.f;
+#pragma unroll
+    for (int kw = 2; kw >= 0; --kw) {
+      const int j2 = q - kw;
+      if (j2 >= 0 && !(j2 & 1) && (j2 >> 1) < SA_B0_FO) s += s9[j2 >> 1][3 * kh + kw];
+    }
+    part[((size_t)row * 3 + kh) * (SA_B0_F + 2) + q] = s;
+  }
+}
+
+// d x[b][t][f] = sum over the padded positions (p, q) that read (t, f), over the output rows i and taps kh
+// with 2 i + kh = p, of part[b][i][kh][q] -- a fixed order, no atomics
+__global__ void asr_block0_fold_kernel(const float* __restrict__ part, bf16_t* __restrict__ dx, int B, int T, int To) {
+  const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= (long long)B * T * SA_B0_F) return;
+  const int f = (int)(idx % SA_B0_F);
+  const int t = (int)((idx / SA_B0_F) % T);
+  const int b = (int)(idx / ((long long)SA_B0_F * T));
+  int ps[3], qs[3], np = 0, nq = 0;
+  ps[np++] = t + 1;
+  if (t == 1) ps[np++] = 0;
+  if (t == T - 2) ps[np++] = T + 1;
+  qs[nq++] = f + 1;
+  if (f == 1) qs[nq++] = 0;
+  if (f == SA_B0_F - 2) qs[nq++] = SA_B0_F + 1;
+  float s = 0.f;
+  for (int a = 0; a < np; ++a)
+    for (int kh = 0; kh < 3; ++kh) {
+      const int i2 = ps[a] - kh;
+      if (i2 < 0 || (i2 & 1) || (i2 >> 1) >= To) continue;
+      const float* pr = part + (((size_t)b * To + (i2 >> 1)) * 3 + kh) * (SA_B0_F + 2);
+      for (int e = 0; e < nq; ++e) s += pr[qs[e]];
+    }
+  dx[idx] = (bf16_t)s;
+}
+
+extern "C" int sa_asr_block0_fwd(const void* x, const void* w, const void* bias, const void* gamma, const void* beta,
+                                 void* y, float* stat, int B, int T, int F, int C, float eps, float slope,
+                                 void* stream) {
+  if (!x || !w || !bias || !gamma || !beta || !y || B <= 0 || T < 3) return -22;
+  if (F != SA_B0_F || C != SA_B0_C) return -38;
+  const int To = (T - 1) / 2 + 1;
+  hipLaunchKernelGGL(asr_block0_fwd_kernel, dim3(B * To), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
+                     (const bf16_t*)x, (const bf16_t*)w, (const bf16_t*)bias, (const bf16_t*)gamma, (const bf16_t*)beta,
+                     (bf16_t*)y, stat, T, To, eps, slope);
+  hipError_t e = hipGetLastError();
+  return e == hipSuccess ? 0 : -(int)e;
+}
+
+extern "C" int sa_asr_block0_bwd(const void* dy, const void* x, const void* w, const void* bias, const void* gamma,
+                                 const void* beta, const float* stat, float* part, void* dx, int B, int T, int F,
+                                 int C, float slope, void* stream) {
+  if (!dy || !x || !w || !bias || !gamma || !beta || !stat || !part || !dx || B <= 0 || T < 3) return -22;
+  if (F != SA_B0_F || C != SA_B0_C) return -38;
+  const int To = (T - 1) / 2 + 1;
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  hipLaunchKernelGGL(asr_block0_bwd_kernel, dim3(B * To), dim3(256), 0, st, (const bf16_t*)dy, (const bf16_t*)x,
+                     (const bf16_t*)w, (const bf16_t*)bias, (const bf16_t*)gamma, (const bf16_t*)beta, stat, part, T, To,
+                     slope);
+  const long long total = (long long)B * T * SA_B0_F;
+  hipLaunchKernelGGL(asr_block0_fold_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, part,
+                     (bf16_t*)dx, B, T, To);
+  hipError_t e = hipGetLastError();
+  return e == hipSuccess ? 0 : -(int)e;
+}

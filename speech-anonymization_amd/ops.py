@@ -736,3 +736,25 @@ def ln_leaky_bwd(dy, x, stat, gamma, beta, slope):
     L.check(L.load().sa_ln_leaky_bwd(_f(dy), _f(x), _f(stat), _f(gamma), _f(beta), _f(dx), x.numel() // d, d,
                                      C.c_float(slope), L.stream()), "sa_ln_leaky_bwd")
     return dx
+
+
+def asr_block0(x, w, bias, gamma, beta, eps, slope, save):
+    """x [B, T, 80] bf16 -> leaky(LayerNorm(conv 1 -> 128, 3 x 3, stride 2, reflect "same")) [B, ceil(T/2), 40, 128]"""
+    B, T, F_ = x.shape
+    Cc = w.shape[0]
+    To = (T - 1) // 2 + 1
+    y = torch.empty(B, To, (F_ - 1) // 2 + 1, Cc, dtype=x.dtype, device=x.device)
+    stat = torch.empty(B * To, 2, dtype=torch.float32, device=x.device) if save else None
+    L.check(L.load().sa_asr_block0_fwd(_f(x), _f(w), _f(bias), _f(gamma), _f(beta), _f(y), _f(stat), B, T, F_, Cc,
+                                       C.c_float(eps), C.c_float(slope), L.stream()), "sa_asr_block0_fwd")
+    return y, stat
+
+
+def asr_block0_bwd(dy, x, w, bias, gamma, beta, stat, slope):
+    B, T, F_ = x.shape
+    To = (T - 1) // 2 + 1
+    part = torch.empty(B * To, 3, F_ + 2, dtype=torch.float32, device=x.device)
+    dx = torch.empty_like(x)
+    L.check(L.load().sa_asr_block0_bwd(_f(dy), _f(x), _f(w), _f(bias), _f(gamma), _f(beta), _f(stat), _f(part), _f(dx),
+                                       B, T, F_, w.shape[0], C.c_float(slope), L.stream()), "sa_asr_block0_bwd")
+    return dx

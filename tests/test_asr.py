@@ -288,3 +288,43 @@ def test_layernorm_leakyrelu_kernels_equal_torch(fc):
     def rel(a, bb):
         return float(((a.float() - bb.float()) ** 2).sum() / (bb.float() ** 2).sum())
     assert rel(y, yr) < 2e-5 and rel(x.grad, xr.grad) < 2e-5
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("B,T", [(3, 72), (2, 37), (1, 1008)])
+def test_front_end_block0_kernel_equals_the_library_path(B, T):
+    """sa_asr_block0_fwd / _bwd (reflect-padded Conv2d 1 -> 128, 3 x 3, stride 2 + LayerNorm + LeakyReLU in one
+    pass each way, the convolution recomputed in the backward) against F.pad / F.conv2d / F.layer_norm /
+    F.leaky_relu in fp32 on the same bf16 operands; even and odd T (the reflection at both ends)."""
+    import torch.nn.functional as F
+    torch.manual_seed(B * 100 + T)
+    dev = torch.device("cuda:0")
+    cnn = A.ConvolutionFrontEnd().to(dev).bfloat16()
+    with torch.no_grad():
+        cnn.b[0].copy_(0.1 * torch.randn(128))
+        cnn.ln_w[0].copy_(1.0 + 0.1 * torch.randn(40, 128))
+        cnn.ln_b[0].copy_(0.1 * torch.randn(40, 128))
+    x = torch.randn(B, T, 80, device=dev).bfloat16().requires_grad_()
+    y = A._Block0.apply(x, cnn.w[0], cnn.b[0], cnn.ln_w[0], cnn.ln_b[0], 1e-5, 0.01)
+    dy = torch.randn_like(y)
+    y.backward(dy)
+    xr = x.detach().float().requires_grad_()
+    h = F.pad(xr.unsqueeze(1), (1, 1, 1, 1), mode="reflect")
+    z = F.conv2d(h, cnn.w[0].float(), cnn.b[0].float(), stride=2).permute(0, 2, 3, 1)
+    yr = F.leaky_relu(F.layer_norm(z, (40, 128), cnn.ln_w[0].float(), cnn.ln_b[0].float(), 1e-5), 0.01)
+    yr.backward(dy.float())
+    assert y.shape == yr.shape
+
+    def rel(a, b):
+        return float(((a.float() - b.float()) ** 2).sum() / (b.float() ** 2).sum())
+    assert rel(y, yr) < 5e-5, rel(y, yr)                  # bf16 roundings of z and y
+    assert rel(x.grad, xr.grad) < 2e-4, rel(x.grad, xr.grad)   # + of d z and d x
+    # the whole front end takes the kernel for its first block and gives the same features as without it
+    feats = torch.randn(B, T, 80, device=dev).bfloat16()
+    with torch.no_grad():
+        out = cnn(feats)
+        k0 = cnn.w[0]
+        cnn.w[0] = torch.nn.Parameter(k0.float(), requires_grad=False)      # (dtype mismatch: library path)
+        ref = cnn(feats)
+        cnn.w[0] = k0
+    assert rel(out, ref) < 1e-3
