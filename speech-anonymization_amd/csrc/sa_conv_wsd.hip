@@ -51,6 +51,10 @@
 // workgroup's wave 0; no stamp exists in the normal build.
 #ifdef SA_WSD_STAMPS
 __device__ unsigned long long sa_wsd_dbg[64 * 16];
+__device__ unsigned long long sa_wsd_wg[512 * 2];             // s_memrealtime at entry / exit of every workgroup
+#define WSD_WG_STAMP(i) do { if (lane_ == 0 && wave_ == 0 && blockIdx.x < 512) { \
+  unsigned long long t_; asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); \
+  sa_wsd_wg[blockIdx.x * 2 + (i)] = t_; } } while (0)
 #define WSD_STAMP(it, i) do { if (lane_ == 0 && wave_ == 0 && blockIdx.x == 7 && (it) < 64) { \
   unsigned long long t_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); \
   sa_wsd_dbg[(it) * 16 + (i)] = t_; } } while (0)
@@ -60,9 +64,13 @@ __device__ unsigned long long sa_wsd_dbg[64 * 16];
 extern "C" int sa_wsd_dbg_read(unsigned long long* out) {
   return -(int)hipMemcpyFromSymbol(out, HIP_SYMBOL(sa_wsd_dbg), sizeof(sa_wsd_dbg));
 }
+extern "C" int sa_wsd_wg_read(unsigned long long* out) {
+  return -(int)hipMemcpyFromSymbol(out, HIP_SYMBOL(sa_wsd_wg), sizeof(sa_wsd_wg));
+}
 #else
 #define WSD_STAMP(it, i)
 #define WSD_STAMP_RT(it, i)
+#define WSD_WG_STAMP(i)
 #endif
 
 namespace {
@@ -185,7 +193,7 @@ __device__ __forceinline__ void wsd_body(const SaConvArgs& a, int bcost, int tot
     last = blockIdx.x + 1 == gridDim.x ? total_tiles : inv(ctot * (blockIdx.x + 1) / gridDim.x);
   }
   if (first >= last) return;
-  WSD_STAMP(63, 0); WSD_STAMP_RT(63, 8);
+  WSD_STAMP(63, 0); WSD_STAMP_RT(63, 8); WSD_WG_STAMP(0);
 
   // ---- the weights: this wave's 32 output columns, all taps / channels, hi and lo images ----
   bf16x8 Bh[WS_NTAPS][WS_KSTEPS], Bl[WS_NTAPS][WS_KSTEPS];
@@ -885,7 +893,7 @@ __device__ __forceinline__ void wsd_body(const SaConvArgs& a, int bcost, int tot
     epi_plain(std::integral_constant<int, 1>{}, Tp, block8(a.y, Tp), block8(a.ep_x, Tp), EP == 4 ? block8(a.ep_g2, Tp) : nullptr);
     epi_stats();
   }
-  WSD_STAMP(63, 3); WSD_STAMP_RT(63, 9);
+  WSD_STAMP(63, 3); WSD_STAMP_RT(63, 9); WSD_WG_STAMP(1);
 #undef WS_IDS
 #undef WSD_IMM
 #undef WSD_Q

@@ -69,6 +69,15 @@ for cname in (sys.argv[1:] or ["enc11", "tdnn3"]):
     lib.sa_wsd_dbg_read(buf)
     st = [[buf[i * 16 + j] for j in range(16)] for i in range(64)]
     print(f"== {cname}: {e0.elapsed_time(e1) / 10 * 1e3:.1f} us per launch (stamped build)")
+    wg = (C.c_ulonglong * 1024)()
+    lib.sa_wsd_wg_read(wg)
+    ent = [wg[2 * i] for i in range(512) if wg[2 * i]]
+    ext = [wg[2 * i + 1] for i in range(512) if wg[2 * i]]
+    if ent:
+        t0w = min(ent)
+        life = sorted((b - a) * 0.01 for a, b in zip(ent, ext))
+        print(f"   {len(ent)} workgroups: entries spread over {(max(ent) - t0w) * 0.01:.1f} us, exits from {(min(ext) - t0w) * 0.01:.1f} to "
+              f"{(max(ext) - t0w) * 0.01:.1f} us after the first entry; lifetimes min / median / max {life[0]:.1f} / {life[len(life) // 2]:.1f} / {life[-1]:.1f} us")
     pro = st[63]
     st[63] = [0] * 16
     if pro[0]:
