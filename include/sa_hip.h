@@ -126,7 +126,8 @@ int sa_conv_gemm_set_impl(int impl);
  * (profiling tools name the kernel they time with it) */
 int sa_conv_gemm_route(int dtype, int cin, int cout, int sa, int u, const SaConvArgs* a);
 int sa_conv_pp_set_tile_rows(int rows);
-/* persistent kernels: extra cost of an utterance end in tiles, for the equal-cost tile ranges (tuning) */
+/* persistent kernels: cost of an un-overlapped iteration in QUARTER tiles (an overlapped one costs 4; default 9),
+ * for the equal-cost tile ranges (tuning; 4..64; bit 16: timing A/B of the first-tile overlap) */
 int sa_conv_ws_set_bcost(int tiles);
 int sa_conv_wsd_set_bcost(int tiles);
 

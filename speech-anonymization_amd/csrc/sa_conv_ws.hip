@@ -116,17 +116,26 @@ void sa_conv_ws_kernel(SaConvArgs a, int bcost, int total_tiles) {
   const int wn_ = wave_ % NWN, wm_ = wave_ / NWN;           // this wave's column block / row half (or phase) of the tile
   const int ph_ = UU == 2 ? wm_ % 2 : 0, rh_ = UU == 2 ? wm_ / 2 : wm_;   // output phase, row half
   const int ntap_ = a.taps.ntaps[ph_];                      // (transposed layers: 3 and 2)
-  // This workgroup's contiguous tile range, cut at equal COST: the few tiles around the end of an
-  // utterance run un-overlapped (about `bcost` tiles' worth of extra time per utterance end; measured
-  // with tools/wsd_stamps.py on the data-gradient kernel, which shares this structure), and a launch
-  // ends with its slowest workgroup.  An utterance counts ntiles + bcost.
+  // This workgroup's contiguous tile range, cut at equal COST in quarter tiles: an iteration whose NEXT or
+  // next-but-one tile is an edge tile (the last tiles of an utterance; the wrap into the next one) runs
+  // un-overlapped and costs `pq` (about 2.25 tiles, measured with tools/wsd_stamps.py on the data-gradient
+  // kernel, which shares this structure), an overlapped one 4; every tile carries its own cost, and a launch
+  // ends with its slowest workgroup.
   int first, last;
   {
-    const unsigned long long U = (unsigned long long)a.ntiles + (unsigned)(bcost & 0xffff);
+    const int e_num = a.Lin - WS_ROWS - a.rowmin, e_den = WS_BM * WS_SA;
+    int e_hi = e_num >= 0 ? e_num / e_den : -((-e_num + e_den - 1) / e_den);     // (floor)
+    if (e_hi > a.ntiles - 2) e_hi = a.ntiles - 2;
+    int nt = a.ntiles + 1 - e_hi;                           // tiles t with t + 2 > e_hi
+    if (nt > a.ntiles) nt = a.ntiles;
+    if (nt < 0) nt = 0;
+    const unsigned long long pq = (unsigned)(bcost & 0xffff), ni = (unsigned)(a.ntiles - nt);
+    const unsigned long long U = pq * (unsigned)nt + 4 * ni;
     const unsigned long long ctot = (unsigned long long)(total_tiles / a.ntiles) * U;
-    auto inv = [&](unsigned long long c) {                  // first tile whose cumulative cost reaches c
+    auto inv = [&](unsigned long long c) {                  // tiles wholly in front of cost position c
       const unsigned long long k = c / U, r = c - k * U;
-      const unsigned long long t = k * (unsigned)a.ntiles + (r < (unsigned)a.ntiles ? r : (unsigned)a.ntiles);
+      unsigned long long t = r < 4 * ni ? r / 4 : ni + (r - 4 * ni) / pq;
+      t += k * (unsigned)a.ntiles;
       return (int)(t < (unsigned)total_tiles ? t : (unsigned)total_tiles);
     };
     first = inv(ctot * blockIdx.x / gridDim.x);
@@ -809,7 +818,7 @@ void sa_conv_ws_kernel(SaConvArgs a, int bcost, int total_tiles) {
 }
 
 // extra cost of an utterance end, in tiles (see the kernel's range computation)
-int g_ws_bcost = 4;
+int g_ws_bcost = 9;
 
 template <int MODE, int NT = 5, int HALO = 4, int CC = 128, int CO = CC, int SA = 1, int UU = 1>
 int launch_ws(const SaConvArgs& a, hipStream_t st) {
@@ -859,7 +868,7 @@ int launch_ws(const SaConvArgs& a, hipStream_t st) {
 
 extern "C" int sa_conv_ws_set_bcost(int tiles) {
   // (bit 16, timing A/B only: the first tile of every range takes the plain path, as before round 3's overlap of it)
-  if ((tiles & 0xffff) > 64 || (tiles & ~0x1ffff)) return -22;
+  if ((tiles & 0xffff) < 4 || (tiles & 0xffff) > 64 || (tiles & ~0x1ffff)) return -22;
   g_ws_bcost = tiles;
   return 0;
 }

@@ -176,17 +176,35 @@ __device__ __forceinline__ void wsd_body(const SaConvArgs& a, int bcost, int tot
   asm volatile("" : "+s"(raw_lds_w));
   const int tid = threadIdx.x, lane_ = tid & 63;
   const int wave_ = __builtin_amdgcn_readfirstlane(tid >> 6);
-  // This workgroup's contiguous tile range.  Tiles are not equally expensive: the few tiles around the
-  // end of an utterance run un-overlapped (about `bcost` tiles' worth of extra time per utterance end,
-  // measured: tools/wsd_stamps.py), and the launch ends with its slowest workgroup -- so the ranges are
-  // cut at equal COST, an utterance counting ntiles + bcost.
+  // This workgroup's contiguous tile range.  Tiles are not equally expensive: an iteration whose tile
+  // sits at the start of an utterance or within the last few tiles runs un-overlapped, about 2.25 times
+  // as long (tools/wsd_stamps.py), and the launch ends with its slowest workgroup (at B = 10, a dozen
+  // tiles per workgroup, a cost of the utterance END alone left lifetimes between 82 and 152 us).  The
+  // ranges are cut at equal COST in quarter tiles: 4 per overlapped tile, `pq` per plain one, each tile
+  // carrying its own cost (plain tiles: [0, nh) and [ntiles - nt, ntiles) of every utterance).
   int first, last;
   {
-    const unsigned long long U = (unsigned long long)a.ntiles + (unsigned)(bcost & 0xffff);
+    // (the thresholds of `fast` below, from the launch geometry alone)
+    const int e_lo = a.rowmin < 0 ? (-a.rowmin + WS_TM - 1) / WS_TM : 0;
+    int e_hi = (a.Lin - WS_ROWS - a.rowmin) >> 6;
+    if (e_hi > a.ntiles - 2) e_hi = a.ntiles - 2;
+    int f_hi = e_hi - 2;
+    const int p_hi = (a.Lout - WS_TM) >> 6;
+    if (f_hi > p_hi) f_hi = p_hi;
+    if (f_hi > a.ntiles - 3) f_hi = a.ntiles - 3;
+    const int f_lo = e_lo > 2 ? e_lo - 1 : 1;
+    int nh = f_lo, nt = a.ntiles - 1 - f_hi;
+    if (f_hi < f_lo) { nh = a.ntiles; nt = 0; }             // (a short utterance: every tile is plain)
+    const unsigned long long pq = (unsigned)(bcost & 0xffff), ni = (unsigned)(a.ntiles - nh - nt);
+    const unsigned long long U = pq * (unsigned)(nh + nt) + 4 * ni;
     const unsigned long long ctot = (unsigned long long)(total_tiles / a.ntiles) * U;
-    auto inv = [&](unsigned long long c) {                  // first tile whose cumulative cost reaches c
+    auto inv = [&](unsigned long long c) {                  // tiles wholly in front of cost position c
       const unsigned long long k = c / U, r = c - k * U;
-      const unsigned long long t = k * (unsigned)a.ntiles + (r < (unsigned)a.ntiles ? r : (unsigned)a.ntiles);
+      unsigned long long t;
+      if (r < pq * (unsigned)nh) t = r / pq;
+      else if (r < pq * (unsigned)nh + 4 * ni) t = (unsigned)nh + (r - pq * (unsigned)nh) / 4;
+      else t = (unsigned)nh + ni + (r - pq * (unsigned)nh - 4 * ni) / pq;
+      t += k * (unsigned)a.ntiles;
       return (int)(t < (unsigned)total_tiles ? t : (unsigned)total_tiles);
     };
     first = inv(ctot * blockIdx.x / gridDim.x);
@@ -908,7 +926,7 @@ void sa_conv_wsd_kernel(SaConvArgs a, int bcost, int total_tiles) {
 }
 
 // extra cost of an utterance end, in tiles (see wsd_body; tools/wsd_ablate.py --bcost sweeps it)
-int g_wsd_bcost = 5;
+int g_wsd_bcost = 9;
 
 template <int NT, int HALO, int PRO, int EP>
 int launch_wsd(const SaConvArgs& a, hipStream_t st) {
@@ -997,7 +1015,7 @@ int wsd_variant(int dtype, int cin, int cout, int sa, int u, const SaConvArgs* a
 
 extern "C" int sa_conv_wsd_set_bcost(int tiles) {
   // (bit 16, timing A/B only: the first tile of every range takes the plain path, as before round 3's overlap of it)
-  if ((tiles & 0xffff) > 64 || (tiles & ~0x1ffff)) return -22;
+  if ((tiles & 0xffff) < 4 || (tiles & 0xffff) > 64 || (tiles & ~0x1ffff)) return -22;
   g_wsd_bcost = tiles;
   return 0;
 }

@@ -259,8 +259,8 @@ def conv_gemm(x, wp, bias, cin, cout, sa, u, phases, Lout, s1=None, t1=None, s2=
 
 
 if __import__("os").environ.get("SA_WS_FIRST_PLAIN") == "1":         # timing A/B: first tile of a range on the plain path
-    L.load().sa_conv_ws_set_bcost(4 | 0x10000)
-    L.load().sa_conv_wsd_set_bcost(5 | 0x10000)
+    L.load().sa_conv_ws_set_bcost(9 | 0x10000)
+    L.load().sa_conv_wsd_set_bcost(9 | 0x10000)
 
 WGRAD_TARGET_WGS = {True: 256, False: 512}
 if __import__("os").environ.get("SA_WG_TARGETS"):                    # tuning override "big,small"
