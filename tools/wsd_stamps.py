@@ -21,6 +21,8 @@ _lib.LIB_PATH = so
 from speech_anonymization_amd import _lib as L, ops
 lib = L.load()
 ops.conv_impl(ws=True)
+if os.environ.get("KB_PQ"):                                   # cost of a plain iteration in quarter tiles (default 9)
+    assert lib.sa_conv_wsd_set_bcost(int(os.environ["KB_PQ"])) == 0
 dev = torch.device("cuda:0")
 B = int(os.environ.get("KB_B", "32"))
 CASES = {"enc11": (5, 1, 2, 20160, "in", 1, False), "tdnn0": (5, 1, 0, 20156, "bn", 3, False),
