@@ -80,6 +80,12 @@ for cname in (sys.argv[1:] or ["enc11", "tdnn3"]):
         life = sorted((b - a) * 0.01 for a, b in zip(ent, ext))
         print(f"   {len(ent)} workgroups: entries spread over {(max(ent) - t0w) * 0.01:.1f} us, exits from {(min(ext) - t0w) * 0.01:.1f} to "
               f"{(max(ext) - t0w) * 0.01:.1f} us after the first entry; lifetimes min / median / max {life[0]:.1f} / {life[len(life) // 2]:.1f} / {life[-1]:.1f} us")
+    if ent and os.environ.get("KB_XCD"):
+        lt = [(wg[2 * i + 1] - wg[2 * i]) * 0.01 for i in range(256)]
+        med = lambda v: sorted(v)[len(v) // 2]
+        print("   median lifetime by workgroup index mod 8 (XCD):", " ".join(f"{med(lt[x::8]):.1f}" for x in range(8)))
+        slow = sorted(range(256), key=lambda i: -lt[i])[:12]
+        print("   slowest workgroups:", " ".join(f"{i}:{lt[i]:.0f}" for i in slow))
     pro = st[63]
     st[63] = [0] * 16
     if pro[0]:
