@@ -129,6 +129,14 @@ int sa_conv_pp_set_tile_rows(int rows);
 /* persistent kernels: cost of an un-overlapped iteration in QUARTER tiles (an overlapped one costs 4; default 9),
  * for the equal-cost tile ranges (tuning; 4..64; bit 16: timing A/B of the first-tile overlap) */
 int sa_conv_ws_set_bcost(int tiles);
+/* The eight XCDs of a chip do not run the persistent kernels at one speed (workgroup lifetimes differ by up to
+ * 12 % by XCD, stable within a process, different from chip to chip).  sa_conv_ws_set_xcd_weights: relative speed per
+ * XCD, one byte each (64 = nominal, >= 16); workgroup i (XCD i % 8) gets that share of the tile cost.  Results do
+ * not depend on it.  sa_conv_ws_calibrate_read: entry / exit times (100 MHz ticks) of the up to 512 workgroups
+ * of the most recent sa_conv_wsd launch, [512][2] -- synchronises; the host derives the weights from it
+ * (ops.calibrate_xcd). */
+int sa_conv_ws_set_xcd_weights(const unsigned char* w8);
+int sa_conv_ws_calibrate_read(unsigned long long* life512x2);
 int sa_conv_wsd_set_bcost(int tiles);
 
 /* fp32 master weights -> fragment-major MFMA operand image (K = GEMM reduction channels,

@@ -100,7 +100,7 @@ SYMBOLS = [
     "sa_leaky_affine_bwd", "sa_cluster_mi", "sa_fbank", "sa_fbank_table_elems", "sa_fbank_ntiles", "sa_fbank_scratch_bytes", "sa_fbank_normalize",
     "sa_comm_unique_id", "sa_comm_init", "sa_comm_world", "sa_comm_allreduce", "sa_comm_allreduce_inline", "sa_comm_join", "sa_comm_ncalls",
     "sa_comm_destroy", "sa_head_fwd", "sa_head_bwd", "sa_head_max_rows", "sa_conv_ws_set_bcost", "sa_conv_wsd_set_bcost",
-    "sa_add_layernorm_fwd", "sa_layernorm_bwd", "sa_reflect_pad_fwd", "sa_reflect_pad_bwd", "sa_ln_leaky_fwd", "sa_ln_leaky_bwd", "sa_bias_multi", "sa_asr_block0_fwd", "sa_asr_block0_bwd",
+    "sa_add_layernorm_fwd", "sa_layernorm_bwd", "sa_reflect_pad_fwd", "sa_reflect_pad_bwd", "sa_ln_leaky_fwd", "sa_ln_leaky_bwd", "sa_bias_multi", "sa_asr_block0_fwd", "sa_asr_block0_bwd", "sa_conv_ws_set_xcd_weights", "sa_conv_ws_calibrate_read",
 ]
 
 _lib = None

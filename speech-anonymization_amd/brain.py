@@ -125,6 +125,8 @@ class Brain:
         # among the objects alive at that point is never collected afterwards -- so a host application
         # that embeds the Brain can switch it off
         self.gc_freeze = bool(run_opts.get("gc_freeze", True))
+        # calibrate_xcd (default on; SA_CALIBRATE_XCD=0 switches it off): see on_fit_start
+        self.calibrate_xcd = bool(run_opts.get("calibrate_xcd", os.environ.get("SA_CALIBRATE_XCD", "1") == "1"))
         self.distributed_launch = bool(run_opts.get("distributed_launch", sdist.is_distributed()))
         self.modules = torch.nn.ModuleDict(modules or {})
         # dp_batch_sizes (default "equal"): how the data-parallel ranks' batches relate.  The data
@@ -161,6 +163,12 @@ class Brain:
         for m in self.modules.values():
             if hasattr(m, "dp_batch_sizes"):
                 m.dp_batch_sizes = self.dp_batch_sizes
+        if self.calibrate_xcd and self.device.type == "cuda":
+            # once per process: the XCDs of a chip run the persistent convolution kernels at different speeds
+            # (up to 12 %); their workgroups get tile ranges in proportion (ops.calibrate_xcd, ~0.1 s)
+            from . import ops
+            if ops._xcd_weights is None:
+                ops.calibrate_xcd(self.device)
         self.init_optimizers()
         if self.checkpointer is not None:
             if self.optimizer is not None:

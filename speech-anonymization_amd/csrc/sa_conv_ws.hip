@@ -64,6 +64,8 @@ extern "C" int sa_ws_dbg_read(unsigned long long* out) {
 
 #include "sa_conv_ws_common.h"
 
+extern unsigned long long g_ws_xcd_weights;                  // (defined below, next to its setter)
+
 namespace {
 
 // Filler slots.  With one wave per SIMD a wave issues one instruction (of any kind) per 4 cycles, a
@@ -90,7 +92,7 @@ namespace {
 // 5: one per-channel affine only (the dilated TDNN layers: BatchNorm of the layer below in front)
 template <int MODE, int NT, int HALO, int CC = 128, int CO = CC, int SA = 1, int UU = 1>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1)))
-void sa_conv_ws_kernel(SaConvArgs a, int bcost, int total_tiles) {
+void sa_conv_ws_kernel(SaConvArgs a, int bcost, int total_tiles, unsigned long long xw) {
   typedef WsGeo<CC, NT, HALO, CO, SA, UU> G;
   constexpr int WS_CO = G::CO, WS_SA = G::SA, WS_BM = G::BM;
   static_assert(UU == 1 || MODE == 0, "transposed layers: plain rows");
@@ -138,8 +140,19 @@ void sa_conv_ws_kernel(SaConvArgs a, int bcost, int total_tiles) {
       t += k * (unsigned)a.ntiles;
       return (int)(t < (unsigned)total_tiles ? t : (unsigned)total_tiles);
     };
-    first = inv(ctot * blockIdx.x / gridDim.x);
-    last = blockIdx.x + 1 == gridDim.x ? total_tiles : inv(ctot * (blockIdx.x + 1) / gridDim.x);
+    // (workgroup i runs on XCD i % 8; its share of the cost follows the weight of its XCD: see sa_conv_wsd.hip)
+    unsigned S8 = 0;
+#pragma unroll
+    for (int x = 0; x < 8; ++x) S8 += (unsigned)(xw >> (8 * x)) & 255u;
+    auto prefix = [&](unsigned i) {
+      unsigned pfx = (i >> 3) * S8;
+#pragma unroll
+      for (int x = 0; x < 8; ++x) pfx += x < (int)(i & 7) ? (unsigned)(xw >> (8 * x)) & 255u : 0u;
+      return (unsigned long long)pfx;
+    };
+    const unsigned long long wtot = prefix(gridDim.x);
+    first = inv(ctot * prefix(blockIdx.x) / wtot);
+    last = blockIdx.x + 1 == gridDim.x ? total_tiles : inv(ctot * prefix(blockIdx.x + 1) / wtot);
   }
   if (first >= last) return;
 
@@ -859,12 +872,26 @@ int launch_ws(const SaConvArgs& a, hipStream_t st) {
   }
   const int total = args.ntiles * a.B;
   const int nwg = total < n_cu ? total : n_cu;
-  hipLaunchKernelGGL(kern, dim3(nwg), dim3(256), lds, st, args, g_ws_bcost, total);
+  hipLaunchKernelGGL(kern, dim3(nwg), dim3(256), lds, st, args, g_ws_bcost, total, g_ws_xcd_weights);
   hipError_t e = hipGetLastError();
   return e == hipSuccess ? 0 : -(int)e;
 }
 
 }  // namespace
+
+// relative speed of the eight XCDs under the persistent kernels, one byte each (64 = nominal)
+unsigned long long g_ws_xcd_weights = 0x4040404040404040ull;
+
+extern "C" int sa_conv_ws_set_xcd_weights(const unsigned char* w8) {
+  if (!w8) return -22;
+  unsigned long long v = 0;
+  for (int x = 0; x < 8; ++x) {
+    if (w8[x] < 16) return -22;                              // (a zero weight would starve an XCD's workgroups)
+    v |= (unsigned long long)w8[x] << (8 * x);
+  }
+  g_ws_xcd_weights = v;
+  return 0;
+}
 
 extern "C" int sa_conv_ws_set_bcost(int tiles) {
   // (bit 16, timing A/B only: the first tile of every range takes the plain path, as before round 3's overlap of it)

@@ -73,6 +73,14 @@ extern "C" int sa_wsd_wg_read(unsigned long long* out) {
 #define WSD_WG_STAMP(i)
 #endif
 
+extern unsigned long long g_ws_xcd_weights;                  // (sa_conv_ws.hip)
+// entry / exit time (s_memrealtime, 100 MHz) of every workgroup of the LAST launch: what
+// sa_conv_ws_calibrate_read hands to the host for the per-XCD weights of the tile ranges
+__device__ unsigned long long sa_wsd_life[512 * 2];
+#define WSD_LIFE(i) do { if (threadIdx.x == 0 && blockIdx.x < 512) { \
+  unsigned long long t_; asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); \
+  sa_wsd_life[blockIdx.x * 2 + (i)] = t_; } } while (0)
+
 namespace {
 
 // ---- the slot schedule of one instantiation (compile-time; shared by the filler and the wait counts) ----
@@ -153,7 +161,7 @@ __device__ static inline void wsd_dma16i(const void* gbase, unsigned voff, unsig
 // the reserved registers.
 #define WSD_XR0 240
 template <int NT, int HALO, int PRO, int EP>
-__device__ __forceinline__ void wsd_body(const SaConvArgs& a, int bcost, int total_tiles) {
+__device__ __forceinline__ void wsd_body(const SaConvArgs& a, int bcost, int total_tiles, unsigned long long xw) {
   typedef WsGeo<128, NT, HALO> G;
   typedef WsdSched<NT, HALO, PRO, EP> Sch;
   constexpr int WS_C = 128, WS_TM = 64, WS_KSTEPS = G::KSTEPS, WS_PITCH = G::PITCH, RPP = G::RPP, LPR = G::LPR;
@@ -207,10 +215,23 @@ __device__ __forceinline__ void wsd_body(const SaConvArgs& a, int bcost, int tot
       t += k * (unsigned)a.ntiles;
       return (int)(t < (unsigned)total_tiles ? t : (unsigned)total_tiles);
     };
-    first = inv(ctot * blockIdx.x / gridDim.x);
-    last = blockIdx.x + 1 == gridDim.x ? total_tiles : inv(ctot * (blockIdx.x + 1) / gridDim.x);
+    // (workgroup i runs on XCD i % 8, and the XCDs of one chip do not run this kernel at one speed: its share
+    // of the cost follows the weight of its XCD -- sa_conv_ws_set_xcd_weights, measured per process)
+    unsigned S8 = 0;
+#pragma unroll
+    for (int x = 0; x < 8; ++x) S8 += (unsigned)(xw >> (8 * x)) & 255u;
+    auto prefix = [&](unsigned i) {
+      unsigned pfx = (i >> 3) * S8;
+#pragma unroll
+      for (int x = 0; x < 8; ++x) pfx += x < (int)(i & 7) ? (unsigned)(xw >> (8 * x)) & 255u : 0u;
+      return (unsigned long long)pfx;
+    };
+    const unsigned long long wtot = prefix(gridDim.x);
+    first = inv(ctot * prefix(blockIdx.x) / wtot);
+    last = blockIdx.x + 1 == gridDim.x ? total_tiles : inv(ctot * prefix(blockIdx.x + 1) / wtot);
   }
   if (first >= last) return;
+  WSD_LIFE(0);
   WSD_STAMP(63, 0); WSD_STAMP_RT(63, 8); WSD_WG_STAMP(0);
 
   // ---- the weights: this wave's 32 output columns, all taps / channels, hi and lo images ----
@@ -912,6 +933,7 @@ __device__ __forceinline__ void wsd_body(const SaConvArgs& a, int bcost, int tot
     epi_stats();
   }
   WSD_STAMP(63, 3); WSD_STAMP_RT(63, 9); WSD_WG_STAMP(1);
+  WSD_LIFE(1);
 #undef WS_IDS
 #undef WSD_IMM
 #undef WSD_Q
@@ -921,8 +943,8 @@ __device__ __forceinline__ void wsd_body(const SaConvArgs& a, int bcost, int tot
 
 template <int NT, int HALO, int PRO, int EP>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) __attribute__((amdgpu_num_vgpr(240)))
-void sa_conv_wsd_kernel(SaConvArgs a, int bcost, int total_tiles) {
-  wsd_body<NT, HALO, PRO, EP>(a, bcost, total_tiles);
+void sa_conv_wsd_kernel(SaConvArgs a, int bcost, int total_tiles, unsigned long long xw) {
+  wsd_body<NT, HALO, PRO, EP>(a, bcost, total_tiles, xw);
 }
 
 // extra cost of an utterance end, in tiles (see wsd_body; tools/wsd_ablate.py --bcost sweeps it)
@@ -963,7 +985,7 @@ int launch_wsd(const SaConvArgs& a, hipStream_t st) {
   }
   const int total = args.ntiles * a.B;
   const int nwg = total < n_cu ? total : n_cu;
-  hipLaunchKernelGGL(kern, dim3(nwg), dim3(256), lds, st, args, g_wsd_bcost, total);
+  hipLaunchKernelGGL(kern, dim3(nwg), dim3(256), lds, st, args, g_wsd_bcost, total, g_ws_xcd_weights);
   hipError_t e = hipGetLastError();
   return e == hipSuccess ? 0 : -(int)e;
 }
@@ -1018,6 +1040,11 @@ extern "C" int sa_conv_wsd_set_bcost(int tiles) {
   if ((tiles & 0xffff) < 4 || (tiles & 0xffff) > 64 || (tiles & ~0x1ffff)) return -22;
   g_wsd_bcost = tiles;
   return 0;
+}
+
+extern "C" int sa_conv_ws_calibrate_read(unsigned long long* life512x2) {
+  if (!life512x2) return -22;
+  return -(int)hipMemcpyFromSymbol(life512x2, HIP_SYMBOL(sa_wsd_life), sizeof(sa_wsd_life));
 }
 
 // Does the fused data-gradient kernel serve this launch?  (sa_conv_gemm.hip asks before routing.)

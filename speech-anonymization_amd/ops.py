@@ -758,3 +758,57 @@ def asr_block0_bwd(dy, x, w, bias, gamma, beta, stat, slope):
     L.check(L.load().sa_asr_block0_bwd(_f(dy), _f(x), _f(w), _f(bias), _f(gamma), _f(beta), _f(stat), _f(part), _f(dx),
                                        B, T, F_, w.shape[0], C.c_float(slope), L.stream()), "sa_asr_block0_bwd")
     return dx
+
+
+# ---- per-XCD speed of the persistent kernels (csrc/sa_conv_ws.hip: sa_conv_ws_set_xcd_weights) ----
+_xcd_weights = None
+
+
+def calibrate_xcd(device=None, rounds=2, B=16, Lin=20160, verbose=False):
+    """Measure how fast each of the eight XCDs runs the persistent convolution kernels on THIS chip and hand the
+    relative speeds to the tile-range balancing (workgroup i runs on XCD i % 8).  One synthetic fused
+    data-gradient launch per round (128 -> 128, 5 taps; about 0.6 GB of scratch tensors), per-workgroup
+    lifetimes read back (this synchronises: call it at set-up, not inside a step).  The weights change
+    which workgroup computes which tiles, never a result.  Returns the eight weights (64 = nominal)."""
+    global _xcd_weights
+    lib = L.load()
+    dev = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+    g = torch.Generator().manual_seed(1)
+    x = torch.randn(B, Lin, 128, generator=g).to(dev)
+    y2 = torch.randn(B, Lin, 128, generator=g).to(dev)
+    xe = torch.randn(B, Lin, 128, generator=g).to(dev)
+    w = (torch.randn(128, 128, 5, generator=g) * 0.05).to(dev)
+    wd = pack_weights(w, "conv_dgrad", torch.float32, L.BF16X3)
+    c = [(torch.rand(B, 128, generator=g) + 0.5).to(dev) for _ in range(3)]
+    s1 = (torch.rand(B, 128, generator=g) + 0.5).to(dev)
+    ao = torch.empty(B, Lin, 128, device=dev, dtype=torch.bfloat16)
+    out = torch.empty(B, Lin, 128, device=dev)
+    kw = dict(code=L.BF16X3, want_stats=True, a_out=ao, out=out,
+              nb=dict(x=y2, c1=c[0], c2=c[1], c3=c[2], per_c=False, relu_mask=False, want_colsum=True),
+              ep=dict(mode=1, x=xe, s1=s1, t1=s1, mean=s1, rstd=s1))
+    weights = [64] * 8
+    buf = (C.c_ulonglong * 1024)()
+    for r in range(rounds + 1):
+        L.check(lib.sa_conv_ws_set_xcd_weights((C.c_ubyte * 8)(*weights)), "sa_conv_ws_set_xcd_weights")
+        if r == rounds:
+            break
+        for _ in range(3):
+            conv_gemm(x, wd, None, 128, 128, 1, 1, taps_conv_dgrad_s1(5, 1, 2), Lin, **kw)
+        torch.cuda.synchronize(dev)
+        L.check(lib.sa_conv_ws_calibrate_read(buf), "sa_conv_ws_calibrate_read")
+        life = [[] for _ in range(8)]
+        for i in range(512):
+            if buf[2 * i] and buf[2 * i + 1] > buf[2 * i]:
+                life[i % 8].append(buf[2 * i + 1] - buf[2 * i])
+        if any(len(v) < 4 for v in life):                   # (not the persistent route, or fewer workgroups than expected)
+            break
+        med = [sorted(v)[len(v) // 2] for v in life]
+        # a workgroup's lifetime ~ its share / the speed of its XCD: new speed estimate = share / lifetime
+        speed = [weights[xi] / med[xi] for xi in range(8)]
+        mean = sum(speed) / 8.0
+        weights = [max(32, min(128, int(round(64.0 * sp / mean)))) for sp in speed]
+        if verbose:
+            print(f"[calibrate_xcd] round {r}: median lifetime by XCD (us) {[round(m * 0.01, 1) for m in med]} -> weights {weights}",
+                  flush=True)
+    _xcd_weights = weights
+    return weights
