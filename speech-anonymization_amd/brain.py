@@ -125,8 +125,10 @@ class Brain:
         # among the objects alive at that point is never collected afterwards -- so a host application
         # that embeds the Brain can switch it off
         self.gc_freeze = bool(run_opts.get("gc_freeze", True))
-        # calibrate_xcd (default on; SA_CALIBRATE_XCD=0 switches it off): see on_fit_start
-        self.calibrate_xcd = bool(run_opts.get("calibrate_xcd", os.environ.get("SA_CALIBRATE_XCD", "1") == "1"))
+        # calibrate_xcd (default OFF; SA_CALIBRATE_XCD=1): see on_fit_start.  Measured: the per-XCD medians of one
+        # launch carry 2-3 % of noise, as much as the effect (odd XCDs ~4 % slower than even ones on every chip
+        # seen) -- the calibrated step was 1 % SLOWER (8.85 vs 8.74 ms); the mechanism stays for experiments
+        self.calibrate_xcd = bool(run_opts.get("calibrate_xcd", os.environ.get("SA_CALIBRATE_XCD", "0") == "1"))
         self.distributed_launch = bool(run_opts.get("distributed_launch", sdist.is_distributed()))
         self.modules = torch.nn.ModuleDict(modules or {})
         # dp_batch_sizes (default "equal"): how the data-parallel ranks' batches relate.  The data

@@ -762,6 +762,9 @@ def asr_block0_bwd(dy, x, w, bias, gamma, beta, stat, slope):
 
 # ---- per-XCD speed of the persistent kernels (csrc/sa_conv_ws.hip: sa_conv_ws_set_xcd_weights) ----
 _xcd_weights = None
+if __import__("os").environ.get("SA_XCD_WEIGHTS"):                      # experiment: "65,63,65,63,65,63,65,63"
+    _xcd_weights = [int(v) for v in __import__("os").environ["SA_XCD_WEIGHTS"].split(",")]
+    L.check(L.load().sa_conv_ws_set_xcd_weights((C.c_ubyte * 8)(*_xcd_weights)), "sa_conv_ws_set_xcd_weights")
 
 
 def calibrate_xcd(device=None, rounds=2, B=16, Lin=20160, verbose=False):
