@@ -123,6 +123,21 @@ void sa_conv_ws_kernel(SaConvArgs a, int bcost, int total_tiles, unsigned long l
   // un-overlapped and costs `pq` (about 2.25 tiles, measured with tools/wsd_stamps.py on the data-gradient
   // kernel, which shares this structure), an overlapped one 4; every tile carries its own cost, and a launch
   // ends with its slowest workgroup.
+#ifdef SA_WS_OLD_RANGES
+  int first, last;
+  {                                                         // (A/B build only: round 2's ranges, one surcharge behind each utterance)
+    const unsigned long long U = (unsigned long long)a.ntiles + 4u;
+    const unsigned long long ctot = (unsigned long long)(total_tiles / a.ntiles) * U;
+    auto inv = [&](unsigned long long c) {
+      const unsigned long long k = c / U, r = c - k * U;
+      const unsigned long long t = k * (unsigned)a.ntiles + (r < (unsigned)a.ntiles ? r : (unsigned)a.ntiles);
+      return (int)(t < (unsigned)total_tiles ? t : (unsigned)total_tiles);
+    };
+    first = inv(ctot * blockIdx.x / gridDim.x);
+    last = blockIdx.x + 1 == gridDim.x ? total_tiles : inv(ctot * (blockIdx.x + 1) / gridDim.x);
+    (void)xw;
+  }
+#else
   int first, last;
   {
     const int e_num = a.Lin - WS_ROWS - a.rowmin, e_den = WS_BM * WS_SA;
@@ -154,6 +169,7 @@ void sa_conv_ws_kernel(SaConvArgs a, int bcost, int total_tiles, unsigned long l
     first = inv(ctot * prefix(blockIdx.x) / wtot);
     last = blockIdx.x + 1 == gridDim.x ? total_tiles : inv(ctot * prefix(blockIdx.x + 1) / wtot);
   }
+#endif
   if (first >= last) return;
 
   // ---- the weights: this wave's 32 output columns, all taps / channels, hi and lo images ----

@@ -190,6 +190,21 @@ __device__ __forceinline__ void wsd_body(const SaConvArgs& a, int bcost, int tot
   // tiles per workgroup, a cost of the utterance END alone left lifetimes between 82 and 152 us).  The
   // ranges are cut at equal COST in quarter tiles: 4 per overlapped tile, `pq` per plain one, each tile
   // carrying its own cost (plain tiles: [0, nh) and [ntiles - nt, ntiles) of every utterance).
+#ifdef SA_WS_OLD_RANGES
+  int first, last;
+  {                                                         // (A/B build only: round 2's ranges, one surcharge behind each utterance)
+    const unsigned long long U = (unsigned long long)a.ntiles + 5u;
+    const unsigned long long ctot = (unsigned long long)(total_tiles / a.ntiles) * U;
+    auto inv = [&](unsigned long long c) {
+      const unsigned long long k = c / U, r = c - k * U;
+      const unsigned long long t = k * (unsigned)a.ntiles + (r < (unsigned)a.ntiles ? r : (unsigned)a.ntiles);
+      return (int)(t < (unsigned)total_tiles ? t : (unsigned)total_tiles);
+    };
+    first = inv(ctot * blockIdx.x / gridDim.x);
+    last = blockIdx.x + 1 == gridDim.x ? total_tiles : inv(ctot * (blockIdx.x + 1) / gridDim.x);
+    (void)xw;
+  }
+#else
   int first, last;
   {
     // (the thresholds of `fast` below, from the launch geometry alone)
@@ -230,6 +245,7 @@ __device__ __forceinline__ void wsd_body(const SaConvArgs& a, int bcost, int tot
     first = inv(ctot * prefix(blockIdx.x) / wtot);
     last = blockIdx.x + 1 == gridDim.x ? total_tiles : inv(ctot * prefix(blockIdx.x + 1) / wtot);
   }
+#endif
   if (first >= last) return;
   WSD_LIFE(0);
   WSD_STAMP(63, 0); WSD_STAMP_RT(63, 8); WSD_WG_STAMP(0);
