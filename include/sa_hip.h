@@ -104,7 +104,7 @@ typedef struct SaConvArgs {
 } SaConvArgs;
 
 int sa_conv_gemm(int dtype, int cin, int cout, int sa, int u, const SaConvArgs* a, void* stream);
-/* sizeof(SaConvArgs | SaWgradArgs | SaEwArgs | SaPackDesc | SaTaps | SaFinArgs | SaBiasMulti) for which = 0..6: lets a binding
+/* sizeof(SaConvArgs | SaWgradArgs | SaEwArgs | SaPackDesc | SaTaps | SaFinArgs | SaBiasMulti | SaWredMulti) for which = 0..7: lets a binding
  * verify its mirror of these records (the library reads every field) */
 int sa_abi_sizeof(int which);
 int sa_conv_gemm_ntiles(int cin, int cout, int u, int Lout);
@@ -181,6 +181,15 @@ int sa_wgrad(int dtype, int cin, int cout, int sa, int u, const SaWgradArgs* a, 
 int sa_wgrad_kw(int cin, int cout);
 int sa_wgrad_reduce(const float* slabs, float* dst, int nslab, int ntaps, int cin, int cout, int sk,
                     int sn, int st, int accumulate, void* stream);
+/* the reducers of up to SA_WRED_MAX weight gradients in one launch (the end of a backward stage): each record is
+ * the argument list of sa_wgrad_reduce (vec is filled in by the library); same order, same bits */
+#define SA_WRED_MAX 8
+typedef struct SaWredDesc {
+  const float* slabs; float* dst;
+  int nslab, ntaps, cin, cout, sk, sn, st, accumulate, vec, pad_;
+} SaWredDesc;
+typedef struct SaWredMulti { int n, pad_; SaWredDesc d[SA_WRED_MAX]; } SaWredMulti;
+int sa_wgrad_reduce_multi(const SaWredMulti* m, void* stream);
 
 /* ---- single-channel ends (sa_small.hip): encoder.0 Conv1d(1,32,15,p7) / decoder.8
  * Conv1d(32,1,15,p7), models/ConvAutoEncoder.py:142,171 ------------------------------- */

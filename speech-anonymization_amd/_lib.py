@@ -86,6 +86,18 @@ class SaBiasMulti(C.Structure):
     _fields_ = [("n", C.c_int), ("pad_", C.c_int), ("d", SaBiasDesc * BIAS_MAX)]
 
 
+WRED_MAX = 8
+
+
+class SaWredDesc(C.Structure):
+    _fields_ = [("slabs", vp), ("dst", vp)] + [(k, C.c_int) for k in ("nslab", "ntaps", "cin", "cout", "sk", "sn", "st",
+                                                                      "accumulate", "vec", "pad_")]
+
+
+class SaWredMulti(C.Structure):
+    _fields_ = [("n", C.c_int), ("pad_", C.c_int), ("d", SaWredDesc * WRED_MAX)]
+
+
 # every symbol include/sa_hip.h declares (checked by tests/test_abi.py on CPU)
 SYMBOLS = [
     "sa_conv_gemm", "sa_abi_sizeof", "sa_conv_gemm_ntiles", "sa_conv_gemm_ntiles_tm", "sa_conv_gemm_set_tile_rows",
@@ -100,7 +112,7 @@ SYMBOLS = [
     "sa_leaky_affine_bwd", "sa_cluster_mi", "sa_fbank", "sa_fbank_table_elems", "sa_fbank_ntiles", "sa_fbank_scratch_bytes", "sa_fbank_normalize",
     "sa_comm_unique_id", "sa_comm_init", "sa_comm_world", "sa_comm_allreduce", "sa_comm_allreduce_inline", "sa_comm_join", "sa_comm_ncalls",
     "sa_comm_destroy", "sa_head_fwd", "sa_head_bwd", "sa_head_max_rows", "sa_conv_ws_set_bcost", "sa_conv_wsd_set_bcost",
-    "sa_add_layernorm_fwd", "sa_layernorm_bwd", "sa_reflect_pad_fwd", "sa_reflect_pad_bwd", "sa_ln_leaky_fwd", "sa_ln_leaky_bwd", "sa_bias_multi", "sa_asr_block0_fwd", "sa_asr_block0_bwd", "sa_conv_ws_set_xcd_weights", "sa_conv_ws_calibrate_read",
+    "sa_add_layernorm_fwd", "sa_layernorm_bwd", "sa_reflect_pad_fwd", "sa_reflect_pad_bwd", "sa_ln_leaky_fwd", "sa_ln_leaky_bwd", "sa_bias_multi", "sa_asr_block0_fwd", "sa_asr_block0_bwd", "sa_conv_ws_set_xcd_weights", "sa_conv_ws_calibrate_read", "sa_wgrad_reduce_multi",
 ]
 
 _lib = None
@@ -121,7 +133,7 @@ def load():
         _lib = C.CDLL(LIB_PATH)
         for s in SYMBOLS:
             getattr(_lib, s).restype = C.c_int
-        for i, rec in enumerate((SaConvArgs, SaWgradArgs, SaEwArgs, SaPackDesc, SaTaps, SaFinArgs, SaBiasMulti)):
+        for i, rec in enumerate((SaConvArgs, SaWgradArgs, SaEwArgs, SaPackDesc, SaTaps, SaFinArgs, SaBiasMulti, SaWredMulti)):
             if _lib.sa_abi_sizeof(i) != C.sizeof(rec):
                 raise SaHipError(f"{rec.__name__}: binding has {C.sizeof(rec)} bytes, {LIB_PATH} "
                                  f"{_lib.sa_abi_sizeof(i)} -- rebuild the library (stale build?)")

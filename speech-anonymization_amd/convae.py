@@ -133,6 +133,7 @@ class ConvAutoencoder(nn.Module):
         # bias gradients of a backward stage as two launches at the end of the stage (sa_bias_multi)
         # instead of sa_sum_partials + sa_fin_bias per layer
         self.batch_bias = os.environ.get("SA_BATCH_BIAS", "1") == "1"
+        self.batch_wred = os.environ.get("SA_BATCH_WRED", "1") == "1"
         # data-parallel FC head: None = every BatchNorm1d of the head exchanges its sums (any batch
         # split); "equal" = every rank holds a batch as large as this one (what data.shard_indices
         # deals); [b0, b1, ...] = the ranks' batch sizes.  With the sizes known the pooled rows are
@@ -539,7 +540,11 @@ class _ConvAEFn(torch.autograd.Function):
         gc = S["gc"]                                      # all-reduced BatchNorm counts (or None)
         cdev = lambda i: None if gc is None else gc[i:i + 1]
         pw = lambda k, kind: W[(k, kind)]
-        wg = functools.partial(ops.wgrad, code=ops.WGRAD_CODE[model.precision])
+        # the split-K reducers of a stage's weight gradients wait for the end of the stage like the bias
+        # gradients (nobody reads them earlier) and run as one launch (sa_wgrad_reduce_multi)
+        pending_wred = []
+        wg = functools.partial(ops.wgrad, code=ops.WGRAD_CODE[model.precision],
+                               defer=pending_wred if model.batch_wred else None)
         ff = model.fused_finalize
         # with the bf16 operand caches in place the apply pass of every normalised layer whose
         # gradient feeds a convolution moves into that convolution's prologue
@@ -599,6 +604,9 @@ class _ConvAEFn(torch.autograd.Function):
             if pending_bias:
                 ops.bias_multi(pending_bias)
                 pending_bias.clear()
+            if pending_wred:
+                ops.wgrad_reduce_multi(pending_wred)
+                pending_wred.clear()
 
         def in_ep(y, nrm, g2=None):
             """fused-epilogue description of an [InstanceNorm -> swish] backward (stats pass)."""

@@ -667,6 +667,7 @@ extern "C" int sa_abi_sizeof(int which) {
     case 4: return (int)sizeof(SaTaps);
     case 5: return (int)sizeof(SaFinArgs);
     case 6: return (int)sizeof(SaBiasMulti);
+    case 7: return (int)sizeof(SaWredMulti);
     default: return -22;
   }
 }

@@ -579,14 +579,12 @@ extern "C" int sa_wgrad(int dtype, int cin, int cout, int sa, int u, const SaWgr
 // layers.  (Before: 16 outputs x 16 slab lanes, 64-byte segments: 18.6 us for the 84 MB of a
 // 128 -> 128 layer.)
 template <int VEC>
-__global__ __launch_bounds__(256) void sa_wgrad_reduce_kernel(const float* __restrict__ slabs,
-                                                              float* __restrict__ dst, int nslab,
-                                                              int ntaps, int CIN, int COUT, int sk,
-                                                              int sn, int st, int accumulate) {
-  __shared__ double part[3][64 * VEC];
+__device__ __forceinline__ void wred_body(const float* __restrict__ slabs, float* __restrict__ dst, int nslab,
+                                          int ntaps, int CIN, int COUT, int sk, int sn, int st, int accumulate,
+                                          int bx, double (*part)[64 * 4]) {
   const int per = ntaps * CIN * COUT;
   const int lane = threadIdx.x & 63, q = threadIdx.x >> 6;
-  const int i0 = (blockIdx.x * 64 + lane) * VEC;
+  const int i0 = (bx * 64 + lane) * VEC;
   double s[VEC];
 #pragma unroll
   for (int j = 0; j < VEC; ++j) s[j] = 0.0;
@@ -628,6 +626,50 @@ __global__ __launch_bounds__(256) void sa_wgrad_reduce_kernel(const float* __res
       dst[d] = accumulate ? dst[d] + (float)t : (float)t;
     }
   }
+}
+
+template <int VEC>
+__global__ __launch_bounds__(256) void sa_wgrad_reduce_kernel(const float* __restrict__ slabs,
+                                                              float* __restrict__ dst, int nslab,
+                                                              int ntaps, int CIN, int COUT, int sk,
+                                                              int sn, int st, int accumulate) {
+  __shared__ double part[3][64 * 4];
+  wred_body<VEC>(slabs, dst, nslab, ntaps, CIN, COUT, sk, sn, st, accumulate, blockIdx.x, part);
+}
+
+// the reducers of all weight gradients of a backward stage in ONE launch (they are read by nobody before the
+// stage's bucket is reduced): record blockIdx.y, the same per-record kernel bodies, order and bits
+__global__ __launch_bounds__(256) void sa_wgrad_reduce_multi_kernel(SaWredMulti m) {
+  __shared__ double part[3][64 * 4];
+  const SaWredDesc& d = m.d[blockIdx.y];
+  const int per = d.ntaps * d.cin * d.cout;
+  if ((int)blockIdx.x * 64 * d.vec >= per) return;               // (uniform per workgroup)
+  if (d.vec == 4) wred_body<4>(d.slabs, d.dst, d.nslab, d.ntaps, d.cin, d.cout, d.sk, d.sn, d.st, d.accumulate, blockIdx.x, part);
+  else if (d.vec == 2) wred_body<2>(d.slabs, d.dst, d.nslab, d.ntaps, d.cin, d.cout, d.sk, d.sn, d.st, d.accumulate, blockIdx.x, part);
+  else wred_body<1>(d.slabs, d.dst, d.nslab, d.ntaps, d.cin, d.cout, d.sk, d.sn, d.st, d.accumulate, blockIdx.x, part);
+}
+
+static int wred_vec(int per) {                                   // (the choice of sa_wgrad_reduce)
+  if (per % 4 == 0 && per >= 4 * 64 * 256) return 4;
+  if (per % 2 == 0 && per >= 2 * 64 * 256) return 2;
+  return 1;
+}
+
+extern "C" int sa_wgrad_reduce_multi(const SaWredMulti* m, void* stream) {
+  if (!m || m->n <= 0 || m->n > SA_WRED_MAX) return -22;
+  SaWredMulti mm = *m;
+  int gx = 0;
+  for (int j = 0; j < mm.n; ++j) {
+    SaWredDesc& d = mm.d[j];
+    if (!d.slabs || !d.dst || d.nslab <= 0 || d.ntaps <= 0 || d.cin <= 0 || d.cout <= 0) return -22;
+    const int per = d.ntaps * d.cin * d.cout;
+    d.vec = wred_vec(per);
+    const int nb = sa_div_up(per, 64 * d.vec);
+    gx = nb > gx ? nb : gx;
+  }
+  hipLaunchKernelGGL(sa_wgrad_reduce_multi_kernel, dim3(gx, mm.n), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), mm);
+  hipError_t e = hipGetLastError();
+  return e == hipSuccess ? 0 : -(int)e;
 }
 
 extern "C" int sa_wgrad_reduce(const float* slabs, float* dst, int nslab, int ntaps, int cin,

@@ -270,7 +270,7 @@ if __import__("os").environ.get("SA_WG_TARGETS"):                    # tuning ov
 
 def wgrad(x, dy, cin, cout, sa, u, taps, Mrows, dst, dst_strides, s1=None, t1=None, s2=None,
           t2=None, swish=False, accumulate=False, target_wgs=None, code=None, x_pre=False,
-          dy_pre=False):
+          dy_pre=False, defer=None):
     """taps: list of (row_offset, phase) per weight tap.  dst: fp32 parameter-gradient tensor in
     PyTorch layout; dst_strides = (s_ci, s_co, s_tap).  x_pre: x is the bf16 a_out tensor of the
     forward conv_gemm (already transformed; s1..swish are ignored); dy_pre: dy is the bf16 a_out of
@@ -303,9 +303,26 @@ def wgrad(x, dy, cin, cout, sa, u, taps, Mrows, dst, dst_strides, s1=None, t1=No
                          C.byref(a), L.stream()),
             f"sa_wgrad({cin},{cout},{sa},{u})")
     sk, sn, st = dst_strides
+    if defer is not None:           # the reducer joins the others of its backward stage (wgrad_reduce_multi)
+        defer.append((slabs, dst, B * nchunk * kw, nt, cin, cout, sk, sn, st, int(accumulate)))
+        return dst
     L.check(lib.sa_wgrad_reduce(_f(slabs), _f(dst), B * nchunk * kw, nt, cin, cout, sk, sn, st,
                                 int(accumulate), L.stream()), "sa_wgrad_reduce")
     return dst
+
+
+def wgrad_reduce_multi(items):
+    """items: the deferred reducers of wgrad(..., defer=items): (slabs, dst, nslab, ntaps, cin, cout, sk, sn, st,
+    accumulate) each -- one launch per eight of them (sa_wgrad_reduce_multi; same bits as one launch each)"""
+    lib = L.load()
+    for i0 in range(0, len(items), L.WRED_MAX):
+        m = L.SaWredMulti()
+        chunk = items[i0:i0 + L.WRED_MAX]
+        m.n = len(chunk)
+        for d, (slabs, dst, nslab, nt, cin, cout, sk, sn, st, acc) in zip(m.d, chunk):
+            d.slabs, d.dst = slabs.data_ptr(), dst.data_ptr()
+            d.nslab, d.ntaps, d.cin, d.cout, d.sk, d.sn, d.st, d.accumulate = nslab, nt, cin, cout, sk, sn, st, acc
+        L.check(lib.sa_wgrad_reduce_multi(C.byref(m), L.stream()), "sa_wgrad_reduce_multi")
 
 
 def conv1toC(x, w, bias, dtype, flip=False, want_stats=False, ep=None):

@@ -1344,3 +1344,31 @@ def test_batched_bias_gradients_equal_the_per_layer_launches():
         assert torch.equal(db, r), (nb, cc, ncomp)
         exact = part[..., 0].double().sum(dim=(0, 1))
         assert float((db.double() - exact).abs().max()) <= 1e-6 * float(exact.abs().max() + 1.0)
+
+
+def test_batched_wgrad_reducers_equal_the_single_launches():
+    """sa_wgrad_reduce_multi (the split-K reducers of a backward stage in one launch) against one
+    sa_wgrad_reduce per layer: the same kernel body per record -> the same BITS; the three row widths
+    (VEC 4 / 2 / 1 by layer size), PyTorch and transposed destination strides, more records than one launch."""
+    from speech_anonymization_amd import ops, _lib as L
+    import ctypes as C
+    torch.manual_seed(5)
+    d = dev()
+    lib = L.load()
+    layers = [(5, 128, 128, 300), (3, 128, 128, 256), (5, 64, 64, 512), (5, 64, 128, 200), (5, 32, 64, 77), (5, 64, 32, 130),
+              (5, 128, 64, 256), (15, 1, 32, 64), (3, 128, 128, 9), (5, 64, 64, 33)]
+    items, ref = [], []
+    for nt, cin, cout, nslab in layers:
+        slabs = torch.randn(nslab, nt, cin, cout, device=d)
+        transposed = (cin + cout + nt) % 2 == 0
+        shape = (cin, cout, nt) if transposed else (cout, cin, nt)
+        sk, sn, st = (cout * nt, nt, 1) if transposed else (nt, cin * nt, 1)
+        dst = torch.full(shape, float("nan"), device=d)
+        r = torch.empty(shape, device=d)
+        L.check(lib.sa_wgrad_reduce(L.ptr(slabs), L.ptr(r), nslab, nt, cin, cout, sk, sn, st, 0, L.stream()), "sa_wgrad_reduce")
+        items.append((slabs, dst, nslab, nt, cin, cout, sk, sn, st, 0))
+        ref.append(r)
+    ops.wgrad_reduce_multi(items)
+    torch.cuda.synchronize()
+    for it, r in zip(items, ref):
+        assert torch.equal(it[1], r), it[2:6]
