@@ -277,6 +277,14 @@ int sa_reduce_finalize(const SaFinArgs* a, void* stream);
  * the per-tile statistics or column-sum slabs of a data-gradient launch) -- what sa_sum_partials + sa_fin_bias do
  * for one layer, same summation order and bits, as TWO launches for all records (rows: fp64 scratch
  * [nbatch][C] per record). */
+/* clip_grad_norm_(params, max_norm) of speechbrain's check_gradients (speechbrain_convae_train.py:249) on up to
+ * SA_FLATS_MAX flat fp32 gradient buffers (the stage buckets of a backward): total = sqrt(sum g^2),
+ * coef = min(1, max_norm / (total + eps)), g *= coef; partials: fp64 scratch [SA_FLATS_MAX * 64]; total_norm
+ * (optional) receives the norm.  Two launches. */
+#define SA_FLATS_MAX 4
+typedef struct SaFlat { float* p; long long n; } SaFlat;
+typedef struct SaFlats { int n, pad_; SaFlat f[SA_FLATS_MAX]; } SaFlats;
+int sa_clip_grads(const SaFlats* f, float max_norm, float eps, double* partials, float* total_norm, void* stream);
 #define SA_BIAS_MAX 8
 typedef struct SaBiasDesc {
   const float* part; double* rows; float* db;

@@ -87,6 +87,16 @@ class SaBiasMulti(C.Structure):
 
 
 WRED_MAX = 8
+FLATS_MAX = 4
+
+
+class SaFlat(C.Structure):
+    _fields_ = [("p", vp), ("n", C.c_longlong)]
+
+
+class SaFlats(C.Structure):
+    _fields_ = [("n", C.c_int), ("pad_", C.c_int), ("f", SaFlat * FLATS_MAX)]
+
 
 
 class SaWredDesc(C.Structure):
@@ -112,7 +122,7 @@ SYMBOLS = [
     "sa_leaky_affine_bwd", "sa_cluster_mi", "sa_fbank", "sa_fbank_table_elems", "sa_fbank_ntiles", "sa_fbank_scratch_bytes", "sa_fbank_normalize",
     "sa_comm_unique_id", "sa_comm_init", "sa_comm_world", "sa_comm_allreduce", "sa_comm_allreduce_inline", "sa_comm_join", "sa_comm_ncalls",
     "sa_comm_destroy", "sa_head_fwd", "sa_head_bwd", "sa_head_max_rows", "sa_conv_ws_set_bcost", "sa_conv_wsd_set_bcost",
-    "sa_add_layernorm_fwd", "sa_layernorm_bwd", "sa_reflect_pad_fwd", "sa_reflect_pad_bwd", "sa_ln_leaky_fwd", "sa_ln_leaky_bwd", "sa_bias_multi", "sa_asr_block0_fwd", "sa_asr_block0_bwd", "sa_conv_ws_set_xcd_weights", "sa_conv_ws_calibrate_read", "sa_wgrad_reduce_multi",
+    "sa_add_layernorm_fwd", "sa_layernorm_bwd", "sa_reflect_pad_fwd", "sa_reflect_pad_bwd", "sa_ln_leaky_fwd", "sa_ln_leaky_bwd", "sa_bias_multi", "sa_asr_block0_fwd", "sa_asr_block0_bwd", "sa_conv_ws_set_xcd_weights", "sa_conv_ws_calibrate_read", "sa_wgrad_reduce_multi", "sa_clip_grads",
 ]
 
 _lib = None

@@ -897,6 +897,8 @@ class _ConvAEFn(torch.autograd.Function):
             buckets.reduce_stage("encoder")
         buckets.join()
         ctx.S = None
+        # (Brain.check_gradients clips the buckets directly when every .grad is still a view of one of them)
+        model._last_flats = [buckets.flat[st] for st in sdist.StageBuckets.STAGES if need_stage[st]]
         grads = tuple(G[k] if need[k] else None for k in names)
         # autograd's AccumulateGrad adopts a gradient only when nothing else references it (it
         # clones otherwise: 56 copies per step): drop this frame's references explicitly rather than

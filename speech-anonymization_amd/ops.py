@@ -832,3 +832,17 @@ def calibrate_xcd(device=None, rounds=2, B=16, Lin=20160, verbose=False):
                   flush=True)
     _xcd_weights = weights
     return weights
+
+
+def clip_flats(flats, max_norm, eps=1e-6):
+    """torch.nn.utils.clip_grad_norm_ on flat fp32 gradient buffers, in place (sa_clip_grads); returns the norm"""
+    f = L.SaFlats()
+    f.n = len(flats)
+    for d, t in zip(f.f, flats):
+        d.p, d.n = t.data_ptr(), t.numel()
+    dev = flats[0].device
+    partials = torch.empty(L.FLATS_MAX * 64, dtype=torch.float64, device=dev)
+    total = torch.empty((), dtype=torch.float32, device=dev)
+    L.check(L.load().sa_clip_grads(C.byref(f), C.c_float(max_norm), C.c_float(eps), _f(partials), _f(total), L.stream()),
+            "sa_clip_grads")
+    return total

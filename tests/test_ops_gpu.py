@@ -1372,3 +1372,36 @@ def test_batched_wgrad_reducers_equal_the_single_launches():
     torch.cuda.synchronize()
     for it, r in zip(items, ref):
         assert torch.equal(it[1], r), it[2:6]
+
+
+@pytest.mark.parametrize("scale", [0.01, 40.0])
+def test_fused_gradient_clip_equals_torch(scale):
+    """sa_clip_grads (clip_grad_norm_ on flat gradient buffers, two launches) against torch.nn.utils.clip_grad_norm_
+    on the same values as 56-style separate tensors: below the threshold nothing changes (bit-equal), above it the
+    scaled gradients agree to fp32 rounding of the coefficient."""
+    from speech_anonymization_amd import ops
+    torch.manual_seed(3)
+    d = dev()
+    sizes = [890_000 // 4, 620_000 // 4, 155_003]
+    flats = [torch.randn(n, device=d) * scale * 1e-2 for n in sizes]
+    ref_params = []
+    for f in flats:
+        off = 0
+        for n in (7, 128 * 128 * 5, 64, f.numel()):
+            n = min(n, f.numel() - off)
+            if n <= 0:
+                break
+            p = torch.nn.Parameter(torch.zeros(n, device=d))
+            p.grad = f[off:off + n].clone()
+            ref_params.append(p)
+            off += n
+    tn_ref = torch.nn.utils.clip_grad_norm_(ref_params, 5.0)
+    before = [f.clone() for f in flats]
+    tn = ops.clip_flats(flats, 5.0)
+    torch.cuda.synchronize()
+    assert abs(float(tn) - float(tn_ref)) <= 2e-6 * float(tn_ref)
+    got = torch.cat(flats)
+    want = torch.cat([p.grad for p in ref_params])
+    if float(tn_ref) <= 5.0:
+        assert torch.equal(got, torch.cat(before))
+    assert float((got - want).abs().max()) <= 3e-7 * float(want.abs().max())
