@@ -637,10 +637,15 @@ __global__ __launch_bounds__(256) void sa_clip_sumsq_kernel(SaFlats f, double* _
 __global__ __launch_bounds__(256) void sa_clip_scale_kernel(SaFlats f, const double* __restrict__ partials, float max_norm,
                                                             float eps, float* __restrict__ total_norm) {
   __shared__ float coef_s;
+  __shared__ double red[4];
+  // every workgroup adds the f.n * 64 <= 256 partials itself, one per thread, in a fixed tree
+  double d = (int)threadIdx.x < f.n * SA_CLIP_BLKS ? partials[threadIdx.x] : 0.0;
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) d += __shfl_xor(d, o, 64);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = d;
+  __syncthreads();
   if (threadIdx.x == 0) {
-    double t = 0.0;
-    for (int i = 0; i < f.n * SA_CLIP_BLKS; ++i) t += partials[i];
-    const float tn = (float)sqrt(t);
+    const float tn = (float)sqrt((red[0] + red[1]) + (red[2] + red[3]));
     float c = max_norm / (tn + eps);
     coef_s = c < 1.0f ? c : 1.0f;
     if (blockIdx.x == 0 && blockIdx.y == 0 && total_norm) *total_norm = tn;
