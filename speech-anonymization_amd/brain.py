@@ -478,7 +478,8 @@ class SexAnonymizationTraining(Brain):
     # sums in line) are recorded with the step -- fork and join of the side stream are event edges
     # inside the capture -- so every rank replays its own graph and the collectives meet on the
     # wire as in the eager step (same sequence, same sizes, whichever ranks replay or run eagerly).
-    # Falls back to the eager path for gradient accumulation > 1 and on the gloo carrier.
+    # Falls back to the eager path for gradient accumulation > 1 and on any carrier but the library
+    # communicator (distributed.capturable).
     GRAPH_WARMUP = 3
 
     def _graph_key(self, batch):

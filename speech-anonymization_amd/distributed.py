@@ -43,12 +43,14 @@ def dp_active():
 
 
 def capturable():
-    """the data-parallel exchanges can be recorded into a hipGraph: they are RCCL launches on HIP
-    streams (the library communicator, or torch.distributed's nccl backend, whose work objects stay
-    off the watchdog during capture).  gloo reduces on the host: not capturable."""
+    """the data-parallel exchanges can be recorded into a hipGraph: only on the library communicator
+    (sa_comm_*: plain RCCL launches on streams the library owns, forked from and joined to the capturing
+    stream by events).  torch.distributed's nccl backend captured too in most runs of the one-rank
+    rehearsal, but one run of the test suite hung inside the capture (its watchdog thread polls events
+    while the capture is global-mode): the step then runs eagerly on that carrier.  gloo reduces on the host."""
     if not dp_active():
         return True
-    return lib_comm_active() or dist.get_backend() == "nccl"
+    return lib_comm_active()
 
 
 def lib_comm_active():

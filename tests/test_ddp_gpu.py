@@ -193,7 +193,7 @@ def test_rccl_world1_is_the_identity(carrier, sizes):
     p = ctx.Process(target=_rccl_worker, args=(29700 + os.getpid() % 1000 + (carrier == "lib") + 2 * (sizes is None),
                                                q, carrier, sizes))
     p.start()
-    (plain, dp), ok, ncalls = q.get(timeout=600)
+    (plain, dp), ok, ncalls = q.get(timeout=300)
     if carrier == "lib":
         # two steps x (3 stage buckets + the immediate exchanges of one step: 11 with the FC head on
         # the gathered global batch, 13 with one exchange per BatchNorm1d)
@@ -223,7 +223,7 @@ def _graph_worker(port, q, carrier):
     from speech_anonymization_amd.brain import Batch
     torch.cuda.set_device(0)
     sdist.ddp_init_group()
-    assert sdist.dp_active() and sdist.capturable()
+    assert sdist.dp_active() and sdist.capturable() == (carrier == "lib")
     dev = torch.device("cuda:0")
     wav = smoke_step.make_wave(4, 11360)
     runs, calls = [], []
@@ -239,7 +239,7 @@ def _graph_worker(port, q, carrier):
             br.fit_batch(Batch(wav * s_, torch.tensor([1.0, 0.83, 0.61, 1.0]), torch.arange(4) % 2))
         torch.cuda.synchronize()
         calls.append(L._lib.sa_comm_ncalls() - n0 if carrier == "lib" else -1)
-        captured = graph and len(br._graphs) == 1 and all("graph" in e for e in br._graphs.values())
+        captured = graph and len(getattr(br, "_graphs", {})) == 1 and all("graph" in e for e in br._graphs.values())
         runs.append(({k: v.detach().cpu().numpy() for k, v in br.modules["ConvAE"].state_dict().items()
                       if v.dtype.is_floating_point}, captured))
     q.put((runs, calls))
@@ -251,21 +251,22 @@ def _graph_worker(port, q, carrier):
 
 @pytest.mark.parametrize("carrier", ["lib", "torch"])
 def test_hip_graph_records_the_data_parallel_exchanges(carrier):
-    """run_opts hip_graph under data parallelism: the RCCL all-reduces of a step (three stage buckets on
-    the side stream, the statistic sums / counts / gathered head rows in line) are captured with the
-    kernels.  One rank (every collective the identity): parameters after six steps equal the eager
-    data-parallel run's; on the library communicator the enqueue counter shows that only the three
-    eager steps and the capture issued collectives from the host -- the replays carry theirs."""
+    """run_opts hip_graph under data parallelism, on the library communicator: the RCCL all-reduces of a step
+    (three stage buckets on the side stream, the statistic sums / counts / gathered head rows in line) are
+    captured with the kernels.  One rank (every collective the identity): parameters after six steps equal
+    the eager data-parallel run's, and the enqueue counter shows that only the three eager steps and the
+    capture issued collectives from the host -- the replays carry theirs.  On torch.distributed's nccl
+    backend the same run_opts fall back to eager steps (distributed.capturable)."""
     import torch.multiprocessing as mp
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     p = ctx.Process(target=_graph_worker, args=(29800 + os.getpid() % 1000 + (carrier == "lib"), q, carrier))
     p.start()
-    runs, calls = q.get(timeout=600)
+    runs, calls = q.get(timeout=300)
     p.join(timeout=120)
     assert p.exitcode == 0
     (p0, _), (p1, captured) = runs
-    assert captured
+    assert captured == (carrier == "lib")
     for k in p0:
         assert float(np.abs(p0[k] - p1[k]).max()) <= 5e-6 + 2e-5 * float(np.abs(p0[k]).max()), k
     if carrier == "lib":
