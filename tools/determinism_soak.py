@@ -2,7 +2,7 @@
 parameters, fixed batch, pooling noise fixed) N times; every gradient and both outputs must be bit-identical to
 the first run every time (the counted waits, the dummy first-tile epilogue, the reserved in-flight registers and
 the ticketless reductions leave no room for run-to-run differences unless something races).
-  python tools/determinism_soak.py [N=600] [B=32]"""
+  python tools/determinism_soak.py [N=600] [B=32] [samples per utterance]"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -15,7 +15,7 @@ dev = torch.device("cuda:0")
 brain = bench.build_brain(dev, "bf16x3", B)
 model = brain.modules["ConvAE"]
 model.pooling_noise = torch.rand(B, 128)                     # the reference draws it per call: fixed here
-batch = bench.synthetic_batch(B, 0, dev)
+batch = bench.synthetic_batch(B, 0, dev, int(sys.argv[3]) if len(sys.argv) > 3 else None)
 nrm = brain.modules["normalize"]
 state0 = nrm.state.clone()                                  # [count, glob_mean[80], glob_std[80]] on the device
 bn0 = {k: v.clone() for k, v in model.state_dict().items() if "running" in k or "num_batches" in k}
